@@ -1,0 +1,202 @@
+/*
+ * soccer_hip.h — C ABI of libsoccer_hip.so
+ *
+ * MI355X (gfx950) batched implementation of the step/reset hot path of the
+ * Littman-94 grid-soccer Markov game, i.e. of
+ *     SoccerSimultaneousEnv.step   (gym_soccer/envs/soccer_simultaneous_env.py:375-408)
+ *     SoccerSimultaneousEnv.reset  (gym_soccer/envs/soccer_simultaneous_env.py:410-424)
+ * of mimoralea/gym-soccer-littman94, plus the constructor-time rule functions
+ * that give those two their meaning (:60-61, :63-109, :146-165, :202-256,
+ * :296-362, :364-373).  The reference has no FFI of its own (it is pure
+ * Python); these are the entry points a ctypes binding inside that file would
+ * call — see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; no exception crosses
+ *     the ABI.  soccer_last_error(h) gives the message (h may be NULL for
+ *     errors raised before a handle exists).
+ *   - "lane" = one environment instance.  A handle owns the resident state of
+ *     n_lanes lanes on ONE device, a HIP stream and the staged rule tables.
+ *   - unless a parameter says "host", array pointers are DEVICE pointers to
+ *     caller-owned buffers of n_lanes elements; all work is enqueued on the
+ *     handle's stream and is asynchronous (soccer_sync to wait).
+ *   - one handle per host thread; calls on one handle are serialised by its
+ *     stream.
+ *   - state is structure-of-arrays in HBM: row_a,col_a,row_b,col_b int8[n],
+ *     poss uint8[n] (bit0: 0 = A has the ball, 1 = B; bit1: lane needs reset),
+ *     t uint8[n] (steps taken in the episode, 0..max_steps).
+ *
+ * Randomness (replaces the reference's per-env np.random.RandomState,
+ * :57-58, consumed once per step and once per reset through gym's
+ * categorical_sample, :395, :414):
+ *   every batched_reset / batched_step call consumes one "tick" of the handle.
+ *   Lane i at tick k evaluates ONE Philox4x32-10 block with
+ *       key     = (seed & 0xffffffff, seed >> 32)
+ *       counter = (g & 0xffffffff, g >> 32, k & 0xffffffff, k >> 32),  g = lane_offset + i
+ *   words (w0,w1) give the step uniform, words (w2,w3) the reset uniform:
+ *       u = (((uint64)w_hi << 32 | w_lo) >> 11) * 2^-53        (53-bit, in [0,1))
+ *   so results depend on (seed, global lane id, tick) only — never on the
+ *   device count or the launch geometry.  Callers that want to feed their own
+ *   uniforms (e.g. the single-env facade, which keeps the reference's MT19937
+ *   stream on the host) pass u_step / u_reset arrays instead.
+ *   Outcome selection is the reference's: first index whose sequential
+ *   float64 running sum of list probabilities exceeds u, index 0 if none does.
+ */
+#ifndef SOCCER_HIP_H
+#define SOCCER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOCCER_ABI_VERSION 1
+
+/* error codes */
+#define SOCCER_OK            0
+#define SOCCER_E_INVALID    -1   /* bad argument / config (the reference's AssertionError cases) */
+#define SOCCER_E_HIP        -2   /* a HIP runtime call failed */
+#define SOCCER_E_NOMEM      -3
+#define SOCCER_E_STATE      -4   /* call not valid in the handle's current state (e.g. capture) */
+
+/* cfg.flags */
+#define SOCCER_F_AUTORESET   1u  /* lanes that terminate/truncate are reset inside the same step */
+
+/* actions (soccer_simultaneous_env.py:8-12); moves are (dcol,drow) (:24-30) */
+#define SOCCER_NOOP  0
+#define SOCCER_NORTH 1
+#define SOCCER_SOUTH 2
+#define SOCCER_EAST  3
+#define SOCCER_WEST  4
+
+typedef struct soccer_handle soccer_handle;
+typedef struct soccer_graph  soccer_graph;
+
+/* Constructor arguments: SoccerSimultaneousEnv.__init__(width, height, slip_prob, ..., seed)
+ * (soccer_simultaneous_env.py:35) + the batching parameters the reference does not have. */
+typedef struct soccer_config {
+    uint64_t n_lanes;       /* environments resident on this handle (>=1) */
+    int32_t  width;         /* pitch columns WITHOUT the two goal columns, >=5 (:45) */
+    int32_t  height;        /* pitch rows, >=4 (:46) */
+    double   slip_prob;     /* [0,1] (:50) */
+    int32_t  max_steps;     /* truncation limit; the reference hard-codes 100 (:404). 1..250 */
+    int32_t  device;        /* HIP device ordinal */
+    uint64_t seed;          /* Philox key */
+    uint64_t lane_offset;   /* global id of lane 0 (multi-GPU sharding) */
+    uint32_t flags;         /* SOCCER_F_* */
+    uint32_t envs_per_thread; /* 0 = library default; 1,4,8,16 force a vector width */
+    void*    stream;        /* hipStream_t to enqueue on, or NULL: the handle creates its own */
+} soccer_config;
+
+/* batched_step_ex arguments.  Required: act_a, act_b.  Every output may be NULL (skipped). */
+typedef struct soccer_step_args {
+    const int8_t*  act_a;       /* [n] action of player A, 0..4 */
+    const int8_t*  act_b;       /* [n] action of player B, 0..4 */
+    const double*  u_step;      /* [n] uniforms for outcome selection, or NULL: per-lane Philox */
+    const double*  u_reset;     /* [n] uniforms for in-step auto-reset, or NULL: per-lane Philox */
+    uint16_t*      obs;         /* [n] observation index after the step (after auto-reset if it fired) */
+    int8_t*        reward;      /* [n] player A's reward -1/0/+1; B's is the negation (:400-402) */
+    uint8_t*       terminated;  /* [n] done flag of the sampled transition (:403) */
+    uint8_t*       truncated;   /* [n] timestep >= max_steps (:404) */
+    uint8_t*       prob_code;   /* [n] code of the sampled transition's probability, see soccer_prob_table */
+    uint16_t*      final_obs;   /* [n] observation BEFORE auto-reset (equals obs when none fired) */
+} soccer_step_args;
+
+/* batched_rollout arguments: T fused steps with state held in registers.
+ * Step j of the rollout is bit-identical to the j-th of T successive batched_step calls. */
+typedef struct soccer_rollout_args {
+    int32_t        n_steps;     /* T >= 1 */
+    int32_t        sample_actions; /* 0: read act_a/act_b; 1: draw uniform-random actions in-kernel
+                                      from a second Philox block (counter word3 bit31 set):
+                                      a = (w0*5)>>32, b = (w1*5)>>32 */
+    const int8_t*  act_a;       /* [T][n] (row stride act_stride) or NULL when sample_actions */
+    const int8_t*  act_b;
+    int64_t        act_stride;  /* elements between consecutive steps (>= n) */
+    uint16_t*      obs;         /* [T][n] trajectories (row stride out_stride) or NULL */
+    int8_t*        reward;
+    uint8_t*       terminated;
+    uint8_t*       truncated;
+    int64_t        out_stride;
+    int32_t*       return_sum;  /* [n] += sum of A's rewards over the T steps, or NULL */
+    int32_t*       episode_count; /* [n] += episodes finished during the T steps, or NULL */
+} soccer_rollout_args;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int soccer_abi_version(void);
+int soccer_device_count(int* count);
+/* replaces SoccerSimultaneousEnv.__init__ (:35-144): validates like its asserts (:45-46),
+ * derives goal rows/cols (:60-61), classifies and numbers the state tuples (:63-109), builds the
+ * ISD (:146-165) and the move/bounds table (:364-373), uploads them, allocates the SoA state.
+ * Lanes start in the "needs reset" condition (:140). */
+int soccer_create(const soccer_config* cfg, soccer_handle** out);
+int soccer_destroy(soccer_handle* h);
+const char* soccer_last_error(const soccer_handle* h);
+/* np_random.seed(seed) (:411-412): re-key Philox and restart the tick counter at 0. */
+int soccer_seed(soccer_handle* h, uint64_t seed);
+int soccer_sync(soccer_handle* h);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* reset (:410-424) for all lanes (mask NULL) or the lanes with mask[i] != 0.
+ * u_reset NULL: Philox words (w2,w3).  obs (nullable) receives every lane's current observation. */
+int batched_reset(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs);
+/* step (:375-408) for all lanes with per-lane Philox randomness. */
+int batched_step(soccer_handle* h, const int8_t* act_a, const int8_t* act_b,
+                 uint16_t* obs, int8_t* reward, uint8_t* terminated, uint8_t* truncated,
+                 uint8_t* prob_code);
+int batched_step_ex(soccer_handle* h, const soccer_step_args* args);
+int batched_rollout(soccer_handle* h, const soccer_rollout_args* args);
+
+/* ---- state injection / readback (`env.state = tuple`, tests/test_deterministic...py:43) -- */
+/* HOST pointers of n_lanes elements; any pointer may be NULL (field left unchanged / not read).
+ * These synchronise the stream. */
+int soccer_set_state(soccer_handle* h, const int8_t* row_a, const int8_t* col_a,
+                     const int8_t* row_b, const int8_t* col_b, const uint8_t* poss,
+                     const uint8_t* t, const uint8_t* needs_reset);
+int soccer_get_state(soccer_handle* h, int8_t* row_a, int8_t* col_a, int8_t* row_b, int8_t* col_b,
+                     uint8_t* poss, uint8_t* t, uint8_t* needs_reset);
+
+/* ---- rule tables (what the reference exposes as state_space / goal_states / isd) --------- */
+/* n_states = nS (:64,:105-106) incl. the terminal index 0; lut_len = H*(W+2)*H*(W+2)*2 */
+int soccer_dims(const soccer_handle* h, int32_t* n_states, int32_t* lut_len,
+                int32_t* n_isd, int32_t* internal_width);
+/* HOST outputs. lut[(((ra*W+ca)*H+rb)*W+cb)*2+p] = observation index, 0 for goal tuples,
+ * 0xFFFF for unreachable tuples (:73-88); goal_value = +1/-1 for goal tuples (:94-102), else 0;
+ * isd_states[n_isd][5] (:146-165). Any pointer may be NULL. */
+int soccer_get_tables(const soccer_handle* h, uint16_t* lut, int8_t* goal_value, int8_t* isd_states);
+/* HOST output: prob[c*3+k] = slip-combination weight c (0: no slip, 1: B slips, 2: A slips,
+ * 3: both; :211-222, evaluated left to right in float64) times outcome probability 1, 0.5, 0.25
+ * (k = 0,1,2; :326-360).  prob_code values index this table (:241). */
+int soccer_prob_table(const soccer_handle* h, double prob[12]);
+
+/* ---- episode statistics ------------------------------------------------------------------ */
+/* hist[0..2] = episodes finished with A's return -1, 0, +1 since create / soccer_reset_stats;
+ * misuse = lane-steps attempted on lanes that needed reset (the reference's assert, :376).
+ * Synchronises the stream. HOST outputs. */
+int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* misuse);
+int soccer_reset_stats(soccer_handle* h);
+uint64_t soccer_tick(const soccer_handle* h);
+
+/* ---- device memory + timing helpers (so a host without torch can drive the library) ------ */
+int soccer_malloc(soccer_handle* h, size_t bytes, void** dptr);
+int soccer_free(soccer_handle* h, void* dptr);
+int soccer_memcpy_h2d(soccer_handle* h, void* dst, const void* src, size_t bytes); /* sync */
+int soccer_memcpy_d2h(soccer_handle* h, void* dst, const void* src, size_t bytes); /* sync */
+int soccer_memset(soccer_handle* h, void* dst, int value, size_t bytes);           /* async */
+/* HIP events on the handle's stream */
+int soccer_timer_start(soccer_handle* h);
+int soccer_timer_stop(soccer_handle* h, float* elapsed_ms);   /* synchronises */
+
+/* ---- hipGraph capture of a sequence of batched_* calls ------------------------------------ */
+/* Calls between begin and end are recorded instead of executed.  The number of recorded
+ * batched_* calls must be even (the tick lives in device memory in two alternating slots). */
+int soccer_graph_begin(soccer_handle* h);
+int soccer_graph_end(soccer_handle* h, soccer_graph** out);
+int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t replays);
+int soccer_graph_destroy(soccer_handle* h, soccer_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOCCER_HIP_H */

@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the *real* reference.
+
+Runs ONLY in the build container, where the upstream reference is mounted
+read-only at /root/reference.  It is never run on the GPU box and nothing it
+imports travels: the fixtures it writes are plain data (inputs + expected
+outputs) in .npz files.
+
+The reference's one missing dependency is `gym` (setup.py:14, not installed,
+no network).  Four symbols are used (soccer_simultaneous_env.py:2-3,
+gym_soccer/__init__.py:1); this script writes a throw-away stand-in for those
+four symbols into a temp dir (our own ~15 lines, including the one-line
+restatement of gym 0.26.2's `categorical_sample`:
+`argmax(cumsum(asarray(p)) > np_random.random())`) and puts it on sys.path.
+
+What is dumped
+  table_{W}x{H}_s{slip}.npz   complete transition relation (P_readable) with
+                              list order and float64 probabilities, state
+                              classification, observation indices, ISD
+  replay_{W}x{H}_s{slip}.npz  (state, t, joint action, u) vectors pushed through
+                              the real step() with an injected uniform
+  reset_{W}x{H}.npz           reset() with injected uniforms
+  traj_5x4_s{slip}_seed{S}.npz  reset(seed=S) + MT19937-driven episodes through
+                              the real reset()/step(), with the uniforms the
+                              env drew recorded alongside
+  single_5x4_s{slip}_{agent}.npz  single-agent (fixed-opponent) transition table
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import tempfile
+import textwrap
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _install_gym_stand_in():
+    d = tempfile.mkdtemp(prefix="gymstandin_")
+    files = {
+        "gym/__init__.py": "from . import spaces\n",
+        "gym/spaces.py": textwrap.dedent("""
+            class Discrete:
+                def __init__(self, n):
+                    self.n = int(n)
+            class Dict(dict):
+                pass
+            """),
+        "gym/envs/__init__.py": "",
+        "gym/envs/registration.py": "def register(*a, **k):\n    pass\n",
+        "gym/envs/toy_text/__init__.py": "",
+        "gym/envs/toy_text/utils.py": textwrap.dedent("""
+            import numpy as np
+            def categorical_sample(prob_n, np_random):
+                prob_n = np.asarray(prob_n)
+                csprob_n = np.cumsum(prob_n)
+                return np.argmax(csprob_n > np_random.random())
+            """),
+    }
+    for rel, src in files.items():
+        p = os.path.join(d, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(src)
+    sys.path.insert(0, d)
+    sys.path.insert(1, REF)
+    sys.dont_write_bytecode = True
+
+
+class _FixedU:
+    """np_random replacement returning an injected uniform."""
+    def __init__(self, u):
+        self.u = u
+    def random(self):
+        return self.u
+
+
+class _RecordingRS:
+    """Wraps a RandomState and records every uniform the env draws."""
+    def __init__(self, rs):
+        self.rs = rs
+        self.drawn = []
+    def seed(self, s):
+        self.rs.seed(s)
+    def random(self):
+        u = self.rs.random()
+        self.drawn.append(u)
+        return u
+
+
+def slip_tag(s):
+    return ("%g" % s).replace(".", "p")
+
+
+def dump_table(Env, width, height, slip):
+    t0 = time.time()
+    env = Env(width=width, height=height, slip_prob=slip)
+    H, W = env.height, env.width
+    n_tuples = H * W * H * W * 2
+    lut = np.full(n_tuples, 0xFFFF, dtype=np.uint16)
+    kind = np.zeros(n_tuples, dtype=np.uint8)       # 0 unreachable, 1 live, 2 goal
+    goal_value = np.zeros(n_tuples, dtype=np.int8)
+
+    def flat(st):
+        xa, ya, xb, yb, p = st
+        return (((xa * W + ya) * H + xb) * W + yb) * 2 + p
+
+    for st, idx in env.state_space.items():
+        if st == env.TERMINAL_STATE:
+            continue
+        lut[flat(st)] = idx
+        kind[flat(st)] = 1
+    for st, val in env.goal_states.items():
+        lut[flat(st)] = 0
+        kind[flat(st)] = 2
+        goal_value[flat(st)] = int(val)
+    for st in env.unreachable_states:
+        assert kind[flat(st)] == 0
+
+    rows, probs = [], []
+    for st, per_action in env.P_readable.items():
+        for (asa, asb), trans in per_action.items():
+            aa = env.ACTION_STRING_TO_INT[asa]
+            ab = env.ACTION_STRING_TO_INT[asb]
+            for k, (p, ns, r, d) in enumerate(trans):
+                rows.append(tuple(st) + (aa, ab, k) + tuple(ns) + (int(r), int(d)))
+                probs.append(p)
+    rows = np.asarray(rows, dtype=np.int8)
+    probs = np.asarray(probs, dtype=np.float64)
+    out = os.path.join(HERE, "table_%dx%d_s%s.npz" % (width, height, slip_tag(slip)))
+    np.savez_compressed(
+        out,
+        width=np.int32(width), height=np.int32(height), slip=np.float64(slip),
+        nS=np.int32(env.nS), nA=np.int32(env.nA),
+        goal_rows=np.asarray(env.goal_rows, dtype=np.int8),
+        lut=lut, kind=kind, goal_value=goal_value,
+        rows=rows, prob=probs,
+        isd_states=np.asarray([s for _, s in env.isd], dtype=np.int8),
+        isd_probs=np.asarray([p for p, _ in env.isd], dtype=np.float64),
+    )
+    print("  %s: %d rows, nS=%d, %.1fs, %d KB" % (
+        os.path.basename(out), len(rows), env.nS, time.time() - t0, os.path.getsize(out) // 1024))
+    return env
+
+
+def dump_replay(env, width, height, slip, n, seed):
+    """Random (state, t, joint action, u) through the real step()."""
+    rng = np.random.RandomState(seed)
+    keys = list(env.P_readable.keys())           # live + goal tuples
+    live = [k for k in keys if k not in env.goal_states]
+    st_in = np.zeros((n, 5), np.int8); t_in = np.zeros(n, np.int16)
+    act = np.zeros((n, 2), np.int8); u_in = np.zeros(n, np.float64)
+    st_out = np.zeros((n, 5), np.int8); obs = np.zeros(n, np.uint16)
+    r_a = np.zeros(n, np.float64); r_b = np.zeros(n, np.float64)
+    done = np.zeros(n, np.uint8); trunc = np.zeros(n, np.uint8)
+    p_info = np.zeros(n, np.float64); needs_reset = np.zeros(n, np.uint8)
+    special_u = [0.0, 0.25, 0.5, 0.75, 0.2499999999999999, 0.4999999999999999,
+                 0.9999999999999999, 1.0 - 2.0 ** -53, 2.0 ** -53]
+    if slip > 0:
+        c0 = (1 - slip) * (1 - slip)
+        c1 = (1 - slip) * slip * 0.5
+        special_u += [c0, np.nextafter(c0, 0), c0 + c1, c0 + c1 + c1, 0.9999, 0.99999]
+    for i in range(n):
+        st = keys[rng.randint(len(keys))] if rng.rand() < 0.05 else live[rng.randint(len(live))]
+        t = [rng.randint(0, 100), 98, 99, 0][rng.randint(4)] if rng.rand() < 0.3 else rng.randint(0, 100)
+        aa, ab = rng.randint(0, 5), rng.randint(0, 5)
+        u = special_u[rng.randint(len(special_u))] if rng.rand() < 0.15 else rng.random_sample()
+        env.state = st; env.timestep = t; env.needs_reset = False
+        env.np_random = _FixedU(u)
+        o, r, d, tr, info = env.step({"player_a": aa, "player_b": ab})
+        assert o["player_a"] == o["player_b"]
+        st_in[i] = st; t_in[i] = t; act[i] = (aa, ab); u_in[i] = u
+        st_out[i] = env.state; obs[i] = o["player_a"]
+        r_a[i] = r["player_a"]; r_b[i] = r["player_b"]
+        done[i] = d["player_a"]; trunc[i] = tr["player_a"]
+        p_info[i] = info["player_a"]["p"]; needs_reset[i] = env.needs_reset
+    out = os.path.join(HERE, "replay_%dx%d_s%s.npz" % (width, height, slip_tag(slip)))
+    np.savez_compressed(out, width=np.int32(width), height=np.int32(height), slip=np.float64(slip),
+                        state=st_in, t=t_in, action=act, u=u_in,
+                        next_state=st_out, obs=obs, reward_a=r_a, reward_b=r_b,
+                        terminated=done, truncated=trunc, p=p_info, needs_reset=needs_reset)
+    print("  %s: %d vectors, %d KB" % (os.path.basename(out), n, os.path.getsize(out) // 1024))
+
+
+def dump_reset(env, width, height):
+    us = [0.0, 0.2499, 0.25, 0.4999999, 0.5, 0.75, 0.99999, 1.0 - 2.0 ** -53] + \
+        list(np.random.RandomState(5).random_sample(200))
+    states = np.zeros((len(us), 5), np.int8); obs = np.zeros(len(us), np.uint16)
+    p = np.zeros(len(us), np.float64)
+    for i, u in enumerate(us):
+        env.np_random = _FixedU(u)
+        o, info = env.reset()
+        states[i] = env.state; obs[i] = o["player_a"]; p[i] = info["player_a"]["p"]
+        assert env.timestep == 0 and env.needs_reset is False
+    out = os.path.join(HERE, "reset_%dx%d.npz" % (width, height))
+    np.savez_compressed(out, width=np.int32(width), height=np.int32(height),
+                        u=np.asarray(us, np.float64), state=states, obs=obs, p=p)
+    print("  %s: %d vectors" % (os.path.basename(out), len(us)))
+
+
+def dump_traj(Env, slip, seed, n_steps):
+    """MT19937-driven episodes through the real reset()/step() (BASELINE config 1 shape)."""
+    env = Env(width=5, height=4, slip_prob=slip)
+    rec = _RecordingRS(env.np_random)
+    env.np_random = rec
+    actions = np.random.RandomState(123).randint(0, 5, size=(n_steps, 2)).astype(np.int8)
+    obs = np.zeros(n_steps, np.uint16); r_a = np.zeros(n_steps); r_b = np.zeros(n_steps)
+    done = np.zeros(n_steps, np.uint8); trunc = np.zeros(n_steps, np.uint8)
+    p = np.zeros(n_steps); state = np.zeros((n_steps, 5), np.int8)
+    reset_before = np.zeros(n_steps, np.uint8); reset_obs = np.zeros(n_steps, np.uint16)
+    u_step = np.zeros(n_steps); u_reset = np.full(n_steps, -1.0)
+    o, _ = env.reset(seed=seed)
+    first_obs = o["player_a"]; u_first_reset = rec.drawn[-1]
+    for k in range(n_steps):
+        if env.needs_reset:
+            o, _ = env.reset()
+            reset_before[k] = 1; reset_obs[k] = o["player_a"]; u_reset[k] = rec.drawn[-1]
+        o, r, d, tr, info = env.step({"player_a": int(actions[k, 0]), "player_b": int(actions[k, 1])})
+        u_step[k] = rec.drawn[-1]
+        obs[k] = o["player_a"]; r_a[k] = r["player_a"]; r_b[k] = r["player_b"]
+        done[k] = d["player_a"]; trunc[k] = tr["player_a"]; p[k] = info["player_a"]["p"]
+        state[k] = env.state
+    out = os.path.join(HERE, "traj_5x4_s%s_seed%d.npz" % (slip_tag(slip), seed))
+    np.savez_compressed(out, slip=np.float64(slip), seed=np.int64(seed), actions=actions,
+                        first_obs=np.uint16(first_obs), u_first_reset=np.float64(u_first_reset),
+                        obs=obs, reward_a=r_a, reward_b=r_b, terminated=done, truncated=trunc,
+                        p=p, state=state, reset_before=reset_before, reset_obs=reset_obs,
+                        u_step=u_step, u_reset=u_reset)
+    print("  %s: %d steps, %d episodes, %d KB" % (
+        os.path.basename(out), n_steps, int(reset_before.sum()) + 1, os.path.getsize(out) // 1024))
+
+
+def dump_single_agent(Env, slip, learner):
+    """Single-agent mode: the other side follows a fixed dict policy baked into the table
+    (soccer_simultaneous_env.py:54-56,187-188,243-244,266-279)."""
+    from gym_soccer.utils.policies import get_random_policy
+    policy = get_random_policy(761, 5, seed=0)
+    kw = {"player_b_policy": policy} if learner == "player_a" else {"player_a_policy": policy}
+    env = Env(width=5, height=4, slip_prob=slip, **kw)
+    rows, probs = [], []
+    for st, per_action in env.P_readable.items():
+        for asx, trans in per_action.items():
+            a = env.ACTION_STRING_TO_INT[asx]
+            for k, (p, ns, r, d) in enumerate(trans):
+                rows.append(tuple(st) + (a, k) + tuple(ns) + (int(r), int(d)))
+                probs.append(p)
+    out = os.path.join(HERE, "single_5x4_s%s_%s.npz" % (slip_tag(slip), learner))
+    np.savez_compressed(out, slip=np.float64(slip), learner=np.bytes_(learner),
+                        policy=np.asarray([policy[s] for s in range(761)], np.int8),
+                        rows=np.asarray(rows, np.int8), prob=np.asarray(probs, np.float64))
+    print("  %s: %d rows, %d KB" % (os.path.basename(out), len(rows), os.path.getsize(out) // 1024))
+
+
+def main():
+    _install_gym_stand_in()
+    from gym_soccer.envs import SoccerSimultaneousEnv as Env
+    print("reference imported from", REF)
+    for (w, h, s, nrep) in [(5, 4, 0.0, 20000), (5, 4, 0.2, 20000), (5, 4, 0.5, 4000),
+                            (5, 4, 1.0, 4000), (6, 4, 0.0, 4000), (7, 5, 0.0, 4000),
+                            (7, 5, 0.3, 4000)]:
+        env = dump_table(Env, w, h, s)
+        dump_replay(env, w, h, s, nrep, seed=1000 + w * 10 + h)
+        if s == 0.0:
+            dump_reset(env, w, h)
+    for s in (0.0, 0.2):
+        for seed in (0, 7):
+            dump_traj(Env, s, seed, 3000)
+    for learner in ("player_a", "player_b"):
+        dump_single_agent(Env, 0.2, learner)
+
+
+if __name__ == "__main__":
+    main()
