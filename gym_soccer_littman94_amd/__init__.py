@@ -1,0 +1,8 @@
+"""MI355X-native batched Littman-94 grid soccer (step/reset hot path of mimoralea/gym-soccer-littman94).
+
+Host side: Python mirroring the reference's SoccerSimultaneousEnv surface; device side: hand-written
+HIP kernels for gfx950 behind a C ABI (libsoccer_hip.so, include/soccer_hip.h).
+"""
+from .core import DeviceArray, SoccerBatch  # noqa: F401
+
+__all__ = ["SoccerBatch", "DeviceArray"]

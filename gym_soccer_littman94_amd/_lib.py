@@ -1,0 +1,108 @@
+"""ctypes binding of libsoccer_hip.so (include/soccer_hip.h).
+
+There is no Python or CPU fallback for the hot path: if the HIP library is missing or a call
+fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsoccer_hip.so")
+
+OK, E_INVALID, E_HIP, E_NOMEM, E_STATE = 0, -1, -2, -3, -4
+F_AUTORESET = 1
+
+
+class SoccerHipError(RuntimeError):
+    """A HIP runtime failure inside libsoccer_hip.so."""
+
+
+class Config(C.Structure):
+    _fields_ = [("n_lanes", C.c_uint64), ("width", C.c_int32), ("height", C.c_int32),
+                ("slip_prob", C.c_double), ("max_steps", C.c_int32), ("device", C.c_int32),
+                ("seed", C.c_uint64), ("lane_offset", C.c_uint64), ("flags", C.c_uint32),
+                ("envs_per_thread", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [("act_a", C.c_void_p), ("act_b", C.c_void_p), ("u_step", C.c_void_p),
+                ("u_reset", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p),
+                ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("prob_code", C.c_void_p),
+                ("final_obs", C.c_void_p), ("last_return", C.c_void_p)]
+
+
+class RolloutArgs(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("sample_actions", C.c_int32), ("act_a", C.c_void_p),
+                ("act_b", C.c_void_p), ("act_stride", C.c_int64), ("obs", C.c_void_p),
+                ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
+                ("out_stride", C.c_int64), ("return_sum", C.c_void_p), ("episode_count", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/soccer_hip.h declares
+PROTOTYPES = {
+    "soccer_abi_version": (C.c_int, []),
+    "soccer_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "soccer_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "soccer_destroy": (C.c_int, [C.c_void_p]),
+    "soccer_last_error": (C.c_char_p, [C.c_void_p]),
+    "soccer_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "soccer_sync": (C.c_int, [C.c_void_p]),
+    "batched_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "batched_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
+    "batched_step_ex": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
+    "batched_rollout": (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs)]),
+    "soccer_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
+    "soccer_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
+    "soccer_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
+    "soccer_get_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "soccer_prob_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_double * 12)]),
+    "soccer_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_uint64)]),
+    "soccer_reset_stats": (C.c_int, [C.c_void_p]),
+    "soccer_tick": (C.c_uint64, [C.c_void_p]),
+    "soccer_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "soccer_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "soccer_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "soccer_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "soccer_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "soccer_timer_start": (C.c_int, [C.c_void_p]),
+    "soccer_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "soccer_graph_begin": (C.c_int, [C.c_void_p]),
+    "soccer_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "soccer_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "soccer_graph_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsoccer_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libsoccer_hip.so not found at %s — build it with "
+                "`make -C gym_soccer_littman94_amd/csrc` (or __graft_entry__.build()). "
+                "There is no CPU fallback for the batched step/reset path." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(lib, handle, code):
+    """Turn a C-ABI error code into the exception the reference would raise."""
+    if code == OK:
+        return
+    msg = lib.soccer_last_error(handle)
+    msg = msg.decode("utf-8", "replace") if msg else "unknown error"
+    if code == E_INVALID:
+        raise AssertionError(msg)           # the reference's error convention is plain assert
+    if code == E_NOMEM:
+        raise MemoryError(msg)
+    if code == E_STATE:
+        raise RuntimeError(msg)
+    raise SoccerHipError(msg)

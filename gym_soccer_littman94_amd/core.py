@@ -1,0 +1,222 @@
+"""SoccerBatch — object wrapper over one libsoccer_hip handle (N lanes resident on one MI355X).
+
+This is the thin host layer between the gym-style classes (env.py, vector_env.py) and the C ABI.
+It never computes a transition itself: every step/reset is a kernel launch in libsoccer_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, RolloutArgs, StepArgs
+
+
+class DeviceArray:
+    """A caller-owned device buffer allocated through the handle (no torch needed)."""
+
+    def __init__(self, batch, shape, dtype):
+        self.batch = batch
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        batch._check(batch.lib.soccer_malloc(batch.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host):
+        a = np.ascontiguousarray(host, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, "size mismatch: %d vs %d bytes" % (a.nbytes, self.nbytes)
+        b = self.batch
+        b._check(b.lib.soccer_memcpy_h2d(b.h, self.ptr, a.ctypes.data, self.nbytes))
+        return self
+
+    def download(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
+        b = self.batch
+        b._check(b.lib.soccer_memcpy_d2h(b.h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def fill(self, value):
+        b = self.batch
+        b._check(b.lib.soccer_memset(b.h, self.ptr, int(value), self.nbytes))
+        return self
+
+    def row(self, k):
+        """Device pointer of row k of a 2-D buffer."""
+        return self.ptr + int(k) * self.shape[-1] * self.dtype.itemsize
+
+    def free(self):
+        if self.ptr and self.batch.h:
+            self.batch.lib.soccer_free(self.batch.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    """Device pointer of a DeviceArray / torch tensor / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):          # torch tensor on the handle's device
+        return x.data_ptr()
+    raise TypeError("expected a DeviceArray, a device tensor or an integer address, got %r" % type(x))
+
+
+class SoccerBatch:
+    """N lanes of the Littman-94 soccer game resident on one GPU.
+
+    Constructor arguments mirror SoccerSimultaneousEnv.__init__
+    (gym_soccer/envs/soccer_simultaneous_env.py:35); failed validations raise AssertionError as the
+    reference's asserts do (:45-46).
+    """
+
+    def __init__(self, n_lanes, width=5, height=4, slip_prob=0.0, seed=0, autoreset=False,
+                 max_steps=100, device=0, lane_offset=0, stream=None, envs_per_thread=0):
+        self.lib = _lib.load()
+        self.h = None
+        cfg = Config(n_lanes=int(n_lanes), width=int(width), height=int(height),
+                     slip_prob=float(slip_prob), max_steps=int(max_steps), device=int(device),
+                     seed=int(seed) & 0xFFFFFFFFFFFFFFFF, lane_offset=int(lane_offset),
+                     flags=_lib.F_AUTORESET if autoreset else 0,
+                     envs_per_thread=int(envs_per_thread), stream=stream)
+        h = C.c_void_p()
+        _lib.check(self.lib, None, self.lib.soccer_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.n = int(n_lanes)
+        self.width, self.height, self.slip_prob = int(width), int(height), float(slip_prob)
+        self.autoreset, self.max_steps = bool(autoreset), int(max_steps)
+        self.device, self.lane_offset = int(device), int(lane_offset)
+        ns, ll, ni, iw = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.soccer_dims(self.h, C.byref(ns), C.byref(ll), C.byref(ni), C.byref(iw)))
+        self.nS, self.lut_len, self.n_isd, self.internal_width = ns.value, ll.value, ni.value, iw.value
+        self.nA = 5
+        pt = (C.c_double * 12)()
+        self._check(self.lib.soccer_prob_table(self.h, C.byref(pt)))
+        self.prob_table = np.array(pt, dtype=np.float64)
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, code):
+        _lib.check(self.lib, self.h, code)
+
+    def close(self):
+        if self.h:
+            self.lib.soccer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def sync(self):
+        self._check(self.lib.soccer_sync(self.h))
+
+    def seed(self, seed):
+        self._check(self.lib.soccer_seed(self.h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    @property
+    def tick(self):
+        return int(self.lib.soccer_tick(self.h))
+
+    # -- tables ---------------------------------------------------------------------------------
+    def tables(self):
+        lut = np.zeros(self.lut_len, np.uint16)
+        goal_value = np.zeros(self.lut_len, np.int8)
+        isd = np.zeros((self.n_isd, 5), np.int8)
+        self._check(self.lib.soccer_get_tables(self.h, lut.ctypes.data, goal_value.ctypes.data, isd.ctypes.data))
+        return lut, goal_value, isd
+
+    # -- hot path -------------------------------------------------------------------------------
+    def reset(self, mask=None, u_reset=None, obs=None):
+        self._check(self.lib.batched_reset(self.h, _ptr(mask), _ptr(u_reset), _ptr(obs)))
+
+    def step(self, act_a, act_b, obs=None, reward=None, terminated=None, truncated=None,
+             prob_code=None, u_step=None, u_reset=None, final_obs=None, last_return=None):
+        a = StepArgs(_ptr(act_a), _ptr(act_b), _ptr(u_step), _ptr(u_reset), _ptr(obs), _ptr(reward),
+                     _ptr(terminated), _ptr(truncated), _ptr(prob_code), _ptr(final_obs), _ptr(last_return))
+        self._check(self.lib.batched_step_ex(self.h, C.byref(a)))
+
+    def step_plain(self, act_a, act_b, obs, reward, terminated, truncated, prob_code=None):
+        """The 8-argument batched_step entry point (per-lane Philox)."""
+        self._check(self.lib.batched_step(self.h, _ptr(act_a), _ptr(act_b), _ptr(obs), _ptr(reward),
+                                          _ptr(terminated), _ptr(truncated), _ptr(prob_code)))
+
+    def rollout(self, n_steps, act_a=None, act_b=None, act_stride=0, sample_actions=False, obs=None,
+                reward=None, terminated=None, truncated=None, out_stride=0, return_sum=None,
+                episode_count=None):
+        a = RolloutArgs(int(n_steps), 1 if sample_actions else 0, _ptr(act_a), _ptr(act_b), int(act_stride),
+                        _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated), int(out_stride),
+                        _ptr(return_sum), _ptr(episode_count))
+        self._check(self.lib.batched_rollout(self.h, C.byref(a)))
+
+    # -- state injection / readback -----------------------------------------------------------
+    def set_state(self, row_a=None, col_a=None, row_b=None, col_b=None, poss=None, t=None, needs_reset=None):
+        def arr(x, dt):
+            if x is None:
+                return None, None
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dt), (self.n,)), dt)
+            return a, a.ctypes.data
+        keep = []
+        ptrs = []
+        for x, dt in ((row_a, np.int8), (col_a, np.int8), (row_b, np.int8), (col_b, np.int8),
+                      (poss, np.uint8), (t, np.uint8), (needs_reset, np.uint8)):
+            a, p = arr(x, dt); keep.append(a); ptrs.append(p)
+        code = self.lib.soccer_set_state(self.h, *ptrs)
+        if code == _lib.E_INVALID:
+            msg = self.lib.soccer_last_error(self.h).decode()
+            if "not a reachable state tuple" in msg:
+                raise KeyError(msg)        # the reference's P_readable[self.state] lookup (:394)
+        self._check(code)
+
+    def get_state(self):
+        n = self.n
+        out = {k: np.zeros(n, np.int8) for k in ("row_a", "col_a", "row_b", "col_b")}
+        out.update({k: np.zeros(n, np.uint8) for k in ("poss", "t", "needs_reset")})
+        self._check(self.lib.soccer_get_state(self.h, *[out[k].ctypes.data for k in
+                    ("row_a", "col_a", "row_b", "col_b", "poss", "t", "needs_reset")]))
+        return out
+
+    # -- statistics / timing ------------------------------------------------------------------
+    def stats(self):
+        hist = (C.c_uint64 * 3)(); mis = C.c_uint64()
+        self._check(self.lib.soccer_get_stats(self.h, C.byref(hist), C.byref(mis)))
+        return np.array(hist, dtype=np.uint64), int(mis.value)
+
+    def reset_stats(self):
+        self._check(self.lib.soccer_reset_stats(self.h))
+
+    def timer_start(self):
+        self._check(self.lib.soccer_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(self.lib.soccer_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    # -- hipGraph capture ----------------------------------------------------------------------
+    def graph_begin(self):
+        self._check(self.lib.soccer_graph_begin(self.h))
+
+    def graph_end(self):
+        g = C.c_void_p()
+        self._check(self.lib.soccer_graph_end(self.h, C.byref(g)))
+        return g
+
+    def graph_launch(self, g, replays=1):
+        self._check(self.lib.soccer_graph_launch(self.h, g, int(replays)))
+
+    def graph_destroy(self, g):
+        self.lib.soccer_graph_destroy(self.h, g)

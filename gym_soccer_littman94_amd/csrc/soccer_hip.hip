@@ -1,0 +1,609 @@
+// soccer_hip.hip — C-ABI implementation of libsoccer_hip.so (see include/soccer_hip.h).
+//
+// Host side: validates arguments the way the reference's asserts do, builds the rule tables
+// (soccer_rules.hpp), owns the resident SoA state, and enqueues the kernels of soccer_kernels.hpp
+// on the handle's HIP stream.  There is no CPU execution path in this library: every batched_* call
+// is a kernel launch, and a missing/failed device is an error, not a fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/soccer_hip.h"
+#include "soccer_kernels.hpp"
+#include "soccer_rules.hpp"
+
+using namespace soccer;
+
+struct soccer_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t ticks = 0;       // ticks consumed by one replay
+};
+
+struct soccer_handle {
+    soccer_config cfg{};
+    Rules rules;
+    KernelParams P{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // device buffers owned by the handle
+    uint16_t* d_lut = nullptr; uint16_t* d_nc = nullptr;
+    unsigned long long* d_tick = nullptr;   // two slots, 128 B apart
+    unsigned long long* d_hist = nullptr;
+    unsigned int* d_misuse = nullptr;
+    int tick_slot = 0;                      // slot the NEXT launch reads
+    uint64_t tick = 0;                      // host mirror of the device tick
+    bool slip = false, lut_lds = true;
+    size_t smem_bytes = 0;
+    int E = 4;
+    int grid_cap = 2048;
+    bool capturing = false;
+    uint64_t capture_ticks = 0;
+    int capture_calls = 0;
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int fail(soccer_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((h), e_ == hipErrorOutOfMemory ? SOCCER_E_NOMEM : SOCCER_E_HIP,          \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                          \
+    } while (0)
+
+template <typename T>
+static bool aligned(const T* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int soccer_abi_version(void) { return SOCCER_ABI_VERSION; }
+
+extern "C" int soccer_device_count(int* count) {
+    if (!count) return fail(nullptr, SOCCER_E_INVALID, "count is NULL");
+    HIP_TRY(nullptr, hipGetDeviceCount(count));
+    return SOCCER_OK;
+}
+
+extern "C" const char* soccer_last_error(const soccer_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+static void free_handle(soccer_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->P.row_a, h->P.col_a, h->P.row_b, h->P.col_b, h->P.poss, h->P.t,
+                    h->d_lut, h->d_nc, h->d_tick, h->d_hist, h->d_misuse};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static void set_key(soccer_handle* h, uint64_t seed) {
+    h->cfg.seed = seed;
+    h->P.key0 = static_cast<uint32_t>(seed);
+    h->P.key1 = static_cast<uint32_t>(seed >> 32);
+}
+
+template <int E, bool SLIP, bool LUT_LDS>
+static hipError_t raise_smem_limit(size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<E, SLIP, LUT_LDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<E, SLIP, LUT_LDS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
+    if (!cfg || !out) return fail(nullptr, SOCCER_E_INVALID, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->n_lanes < 1) return fail(nullptr, SOCCER_E_INVALID, "n_lanes must be >= 1");
+    if (!(cfg->slip_prob >= 0.0 && cfg->slip_prob <= 1.0))
+        return fail(nullptr, SOCCER_E_INVALID, "slip_prob must be in [0, 1]");
+    if (cfg->max_steps < 1 || cfg->max_steps > 250)
+        return fail(nullptr, SOCCER_E_INVALID, "max_steps must be in 1..250 (timestep is a uint8)");
+    const uint32_t e = cfg->envs_per_thread;
+    if (!(e == 0 || e == 1 || e == 4 || e == 8))
+        return fail(nullptr, SOCCER_E_INVALID, "envs_per_thread must be 0, 1, 4 or 8");
+    soccer_handle* h = new soccer_handle();
+    h->cfg = *cfg;
+    const std::string msg = h->rules.build(cfg->width, cfg->height);
+    if (!msg.empty()) { delete h; return fail(nullptr, SOCCER_E_INVALID, "%s", msg.c_str()); }
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev < 1) {
+        delete h;
+        return fail(nullptr, SOCCER_E_HIP, "no HIP device available (%s); libsoccer_hip has no CPU path",
+                    de == hipSuccess ? "device count is 0" : hipGetErrorString(de));
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) {
+        delete h; return fail(nullptr, SOCCER_E_INVALID, "device %d out of range (0..%d)", cfg->device, ndev - 1);
+    }
+#define CREATE_TRY(expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            int code_ = fail(nullptr, e_ == hipErrorOutOfMemory ? SOCCER_E_NOMEM : SOCCER_E_HIP,  \
+                             "%s failed: %s", #expr, hipGetErrorString(e_));                      \
+            free_handle(h); return code_;                                                         \
+        }                                                                                         \
+    } while (0)
+    CREATE_TRY(hipSetDevice(cfg->device));
+    if (cfg->stream) { h->stream = static_cast<hipStream_t>(cfg->stream); h->own_stream = false; }
+    else { CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+
+    const Rules& R = h->rules;
+    KernelParams& P = h->P;
+    const size_t n = cfg->n_lanes;
+    const size_t padded = (n + 63) & ~size_t(63);
+    CREATE_TRY(hipMalloc(&P.row_a, padded)); CREATE_TRY(hipMalloc(&P.col_a, padded));
+    CREATE_TRY(hipMalloc(&P.row_b, padded)); CREATE_TRY(hipMalloc(&P.col_b, padded));
+    CREATE_TRY(hipMalloc(&P.poss, padded));  CREATE_TRY(hipMalloc(&P.t, padded));
+    // every lane starts needing a reset (:140), parked on the first ISD state so the tuple is valid
+    CREATE_TRY(hipMemsetAsync(P.row_a, R.isd[0][0], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(P.col_a, R.isd[0][1], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(P.row_b, R.isd[0][2], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(P.col_b, R.isd[0][3], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(P.poss, 2 | R.isd[0][4], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(P.t, 0, padded, h->stream));
+
+    CREATE_TRY(hipMalloc(&h->d_lut, R.lut.size() * sizeof(uint16_t)));
+    CREATE_TRY(hipMalloc(&h->d_nc, R.next_cell.size() * sizeof(uint16_t)));
+    CREATE_TRY(hipMemcpy(h->d_lut, R.lut.data(), R.lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_nc, R.next_cell.data(), R.next_cell.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&h->d_tick, 256));
+    CREATE_TRY(hipMemset(h->d_tick, 0, 256));
+    CREATE_TRY(hipMalloc(&h->d_hist, sizeof(unsigned long long) * kHistShards * kHistStride));
+    CREATE_TRY(hipMemset(h->d_hist, 0, sizeof(unsigned long long) * kHistShards * kHistStride));
+    CREATE_TRY(hipMalloc(&h->d_misuse, 128));
+    CREATE_TRY(hipMemset(h->d_misuse, 0, 128));
+
+    P.lut = h->d_lut; P.next_cell = h->d_nc;
+    P.hist = h->d_hist; P.misuse = h->d_misuse;
+    P.lane_offset = cfg->lane_offset;
+    P.n = n; P.H = R.H; P.W = R.W; P.HW = R.H * R.W;
+    P.lut_len = static_cast<int32_t>(R.lut.size());
+    P.nc_len = static_cast<int32_t>(R.next_cell.size());
+    P.max_steps = cfg->max_steps;
+    P.autoreset = (cfg->flags & SOCCER_F_AUTORESET) ? 1u : 0u;
+    P.isd_shift = R.n_isd == 4 ? 0u : 1u;
+    for (int i = 0; i < 4; ++i) {
+        const int k = i < R.n_isd ? i : 0;
+        P.isd_pos[i] = (uint32_t)(uint8_t)R.isd[k][0] | ((uint32_t)(uint8_t)R.isd[k][1] << 8) |
+                       ((uint32_t)(uint8_t)R.isd[k][2] << 16) | ((uint32_t)(uint8_t)R.isd[k][3] << 24);
+        P.isd_poss_obs[i] = (uint32_t)R.isd[k][4] | ((uint32_t)R.isd_obs[k] << 16);
+    }
+    // slip-combination weights exactly as the reference writes them, left to right in float64 (:211-222)
+    {
+        volatile double s = cfg->slip_prob;   // volatile: no reassociation / contraction
+        volatile double one_minus = 1 - s;
+        volatile double c0 = one_minus * one_minus;
+        volatile double c1a = one_minus * s;  volatile double c1 = c1a * 0.5;
+        volatile double c2a = s * one_minus;  volatile double c2 = c2a * 0.5;
+        volatile double c3a = s * s;          volatile double c3 = c3a * 0.25;
+        P.w[0] = c0; P.w[1] = c1; P.w[2] = c2; P.w[3] = c3;
+    }
+    set_key(h, cfg->seed);
+    h->slip = cfg->slip_prob != 0.0;
+    h->E = e ? static_cast<int>(e) : 4;
+
+    // LDS budget: move/bounds table always; the observation LUT when it fits next to it
+    const size_t nc_bytes = R.next_cell.size() * sizeof(uint16_t);
+    const size_t lut_bytes = R.lut.size() * sizeof(uint16_t);
+    h->lut_lds = nc_bytes + lut_bytes <= 150 * 1024;
+    h->smem_bytes = nc_bytes + (h->lut_lds ? lut_bytes : 0);
+    if (h->smem_bytes > 48 * 1024) {
+        hipError_t se = hipSuccess;
+        const size_t b = h->smem_bytes;
+#define RAISE(EV) if (se == hipSuccess) { se = h->slip ? (h->lut_lds ? raise_smem_limit<EV, true, true>(b) : raise_smem_limit<EV, true, false>(b)) \
+                                                       : (h->lut_lds ? raise_smem_limit<EV, false, true>(b) : raise_smem_limit<EV, false, false>(b)); }
+        RAISE(1) RAISE(4) RAISE(8)
+#undef RAISE
+        if (se == hipSuccess)
+            se = hipFuncSetAttribute(reinterpret_cast<const void*>(h->lut_lds ? &reset_kernel<true> : &reset_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+        CREATE_TRY(se);
+    }
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    h->grid_cap = prop.multiProcessorCount * 8;
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    *out = h;
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_destroy(soccer_handle* h) {
+    if (!h) return SOCCER_OK;
+    free_handle(h);
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_sync(soccer_handle* h) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_sync during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_seed(soccer_handle* h, uint64_t seed) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_seed during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    set_key(h, seed);
+    h->tick = 0;
+    HIP_TRY(h, hipMemsetAsync(h->d_tick, 0, 256, h->stream));
+    return SOCCER_OK;
+}
+
+extern "C" uint64_t soccer_tick(const soccer_handle* h) { return h ? h->tick : 0; }
+
+// the tick lives in device memory so that a captured graph advances it on every replay: launch j
+// reads slot (j & 1) and writes slot ((j + 1) & 1)
+static void bind_tick(soccer_handle* h, KernelParams& P, uint64_t ticks) {
+    P.tick_in = h->d_tick + (h->tick_slot ? 16 : 0);
+    P.tick_out = h->d_tick + (h->tick_slot ? 0 : 16);
+    h->tick_slot ^= 1;
+    if (h->capturing) { h->capture_ticks += ticks; h->capture_calls += 1; }
+    else h->tick += ticks;
+}
+
+static int grid_for(const soccer_handle* h, uint64_t work_items) {
+    uint64_t blocks = (work_items + kBlock - 1) / kBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > (uint64_t)h->grid_cap) blocks = h->grid_cap;
+    return static_cast<int>(blocks);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int batched_reset(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (!aligned(u_reset, 8) || !aligned(obs, 2))
+        return fail(h, SOCCER_E_INVALID, "batched_reset: u_reset must be 8-byte and obs 2-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    KernelParams P = h->P;
+    bind_tick(h, P, 1);
+    ResetIO io{mask, u_reset, obs};
+    const int grid = grid_for(h, P.n);
+    if (h->lut_lds) hipLaunchKernelGGL(reset_kernel<true>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, P, io);
+    else hipLaunchKernelGGL(reset_kernel<false>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, P, io);
+    HIP_TRY(h, hipGetLastError());
+    return SOCCER_OK;
+}
+
+template <int E>
+static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& io) {
+    const int grid = grid_for(h, (P.n + E - 1) / E);
+    const dim3 g(grid), b(kBlock);
+    if (h->slip) {
+        if (h->lut_lds) hipLaunchKernelGGL((step_kernel<E, true, true>), g, b, h->smem_bytes, h->stream, P, io);
+        else hipLaunchKernelGGL((step_kernel<E, true, false>), g, b, h->smem_bytes, h->stream, P, io);
+    } else {
+        if (h->lut_lds) hipLaunchKernelGGL((step_kernel<E, false, true>), g, b, h->smem_bytes, h->stream, P, io);
+        else hipLaunchKernelGGL((step_kernel<E, false, false>), g, b, h->smem_bytes, h->stream, P, io);
+    }
+}
+
+extern "C" int batched_step_ex(soccer_handle* h, const soccer_step_args* a) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (!a || !a->act_a || !a->act_b) return fail(h, SOCCER_E_INVALID, "batched_step: act_a and act_b are required");
+    if (!aligned(a->u_step, 8) || !aligned(a->u_reset, 8) || !aligned(a->obs, 2) || !aligned(a->final_obs, 2))
+        return fail(h, SOCCER_E_INVALID, "batched_step: u_* must be 8-byte and obs/final_obs 2-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // vector width: every byte stream must be E-aligned, the uint16 streams 2E-aligned
+    int E = h->E;
+    auto ok = [&](int e) {
+        return aligned(a->act_a, e) && aligned(a->act_b, e) && aligned(a->reward, e) && aligned(a->terminated, e) &&
+               aligned(a->truncated, e) && aligned(a->prob_code, e) && aligned(a->obs, 2 * e) && aligned(a->final_obs, 2 * e);
+    };
+    while (E > 1 && !ok(E)) E = E == 4 ? 1 : E / 2;
+    KernelParams P = h->P;
+    bind_tick(h, P, 1);
+    StepIO io{a->act_a, a->act_b, a->u_step, a->u_reset, a->obs, a->reward, a->terminated, a->truncated,
+              a->prob_code, a->final_obs, a->last_return};
+    switch (E) {
+        case 8: launch_step<8>(h, P, io); break;
+        case 4: launch_step<4>(h, P, io); break;
+        default: launch_step<1>(h, P, io); break;
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SOCCER_OK;
+}
+
+extern "C" int batched_step(soccer_handle* h, const int8_t* act_a, const int8_t* act_b, uint16_t* obs,
+                            int8_t* reward, uint8_t* terminated, uint8_t* truncated, uint8_t* prob_code) {
+    soccer_step_args a{};
+    a.act_a = act_a; a.act_b = act_b; a.obs = obs; a.reward = reward;
+    a.terminated = terminated; a.truncated = truncated; a.prob_code = prob_code;
+    return batched_step_ex(h, &a);
+}
+
+template <int E>
+static void launch_rollout(soccer_handle* h, const KernelParams& P, const RolloutIO& io) {
+    const int grid = grid_for(h, (P.n + E - 1) / E);
+    const dim3 g(grid), b(kBlock);
+    if (h->slip) {
+        if (h->lut_lds) hipLaunchKernelGGL((rollout_kernel<E, true, true>), g, b, h->smem_bytes, h->stream, P, io);
+        else hipLaunchKernelGGL((rollout_kernel<E, true, false>), g, b, h->smem_bytes, h->stream, P, io);
+    } else {
+        if (h->lut_lds) hipLaunchKernelGGL((rollout_kernel<E, false, true>), g, b, h->smem_bytes, h->stream, P, io);
+        else hipLaunchKernelGGL((rollout_kernel<E, false, false>), g, b, h->smem_bytes, h->stream, P, io);
+    }
+}
+
+extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (!a || a->n_steps < 1) return fail(h, SOCCER_E_INVALID, "batched_rollout: n_steps must be >= 1");
+    if (!a->sample_actions && (!a->act_a || !a->act_b))
+        return fail(h, SOCCER_E_INVALID, "batched_rollout: act_a/act_b required unless sample_actions");
+    if (!a->sample_actions && a->act_stride < (int64_t)h->P.n)
+        return fail(h, SOCCER_E_INVALID, "batched_rollout: act_stride must be >= n_lanes");
+    const bool any_out = a->obs || a->reward || a->terminated || a->truncated;
+    if (any_out && a->out_stride < (int64_t)h->P.n)
+        return fail(h, SOCCER_E_INVALID, "batched_rollout: out_stride must be >= n_lanes");
+    if (!aligned(a->obs, 2) || !aligned(a->return_sum, 4) || !aligned(a->episode_count, 4))
+        return fail(h, SOCCER_E_INVALID, "batched_rollout: misaligned obs/return_sum/episode_count");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    int E = h->E;
+    auto ok = [&](int e) {
+        const bool strides = (a->sample_actions || a->act_stride % e == 0) && (!any_out || a->out_stride % e == 0);
+        return strides && aligned(a->act_a, e) && aligned(a->act_b, e) && aligned(a->reward, e) &&
+               aligned(a->terminated, e) && aligned(a->truncated, e) && aligned(a->obs, 2 * e) &&
+               aligned(a->return_sum, 4 * e) && aligned(a->episode_count, 4 * e);
+    };
+    while (E > 1 && !ok(E)) E = E == 4 ? 1 : E / 2;
+    KernelParams P = h->P;
+    bind_tick(h, P, (uint64_t)a->n_steps);
+    RolloutIO io{a->n_steps, a->sample_actions, a->act_a, a->act_b, (long long)a->act_stride,
+                 a->obs, a->reward, a->terminated, a->truncated, (long long)a->out_stride,
+                 a->return_sum, a->episode_count};
+    switch (E) {
+        case 8: launch_rollout<8>(h, P, io); break;
+        case 4: launch_rollout<4>(h, P, io); break;
+        default: launch_rollout<1>(h, P, io); break;
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SOCCER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int soccer_set_state(soccer_handle* h, const int8_t* row_a, const int8_t* col_a, const int8_t* row_b,
+                                const int8_t* col_b, const uint8_t* poss, const uint8_t* t,
+                                const uint8_t* needs_reset) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_set_state during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t n = h->P.n;
+    const Rules& R = h->rules;
+    // current device copy of whatever is not supplied, so the resulting tuple can be validated
+    std::vector<int8_t> ra(n), ca(n), rb(n), cb(n);
+    std::vector<uint8_t> ps(n), tt(n);
+    HIP_TRY(h, hipMemcpy(ra.data(), h->P.row_a, n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(ca.data(), h->P.col_a, n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(rb.data(), h->P.row_b, n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(cb.data(), h->P.col_b, n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(ps.data(), h->P.poss, n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(tt.data(), h->P.t, n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        if (row_a) ra[i] = row_a[i];
+        if (col_a) ca[i] = col_a[i];
+        if (row_b) rb[i] = row_b[i];
+        if (col_b) cb[i] = col_b[i];
+        uint8_t p = ps[i] & 1, nr = (ps[i] >> 1) & 1;
+        if (poss) { if (poss[i] > 1) return fail(h, SOCCER_E_INVALID, "lane %zu: possession must be 0 or 1", i); p = poss[i]; }
+        if (needs_reset) nr = needs_reset[i] ? 1 : 0;
+        ps[i] = static_cast<uint8_t>(p | (nr << 1));
+        if (t) { if (t[i] > h->cfg.max_steps) return fail(h, SOCCER_E_INVALID, "lane %zu: timestep %d > max_steps", i, (int)t[i]); tt[i] = t[i]; }
+        const bool in_range = ra[i] >= 0 && ra[i] < R.H && rb[i] >= 0 && rb[i] < R.H &&
+                              ca[i] >= 0 && ca[i] < R.W && cb[i] >= 0 && cb[i] < R.W;
+        // the reference raises KeyError when stepping from a tuple it has no table entry for
+        if (!in_range || R.kind[R.flat(ra[i], ca[i], rb[i], cb[i], p)] == 0)
+            return fail(h, SOCCER_E_INVALID, "lane %zu: state (%d, %d, %d, %d, %d) is not a reachable state tuple",
+                        i, (int)ra[i], (int)ca[i], (int)rb[i], (int)cb[i], (int)p);
+    }
+    HIP_TRY(h, hipMemcpy(h->P.row_a, ra.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->P.col_a, ca.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->P.row_b, rb.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->P.col_b, cb.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->P.poss, ps.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->P.t, tt.data(), n, hipMemcpyHostToDevice));
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_get_state(soccer_handle* h, int8_t* row_a, int8_t* col_a, int8_t* row_b, int8_t* col_b,
+                                uint8_t* poss, uint8_t* t, uint8_t* needs_reset) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_get_state during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t n = h->P.n;
+    if (row_a) HIP_TRY(h, hipMemcpy(row_a, h->P.row_a, n, hipMemcpyDeviceToHost));
+    if (col_a) HIP_TRY(h, hipMemcpy(col_a, h->P.col_a, n, hipMemcpyDeviceToHost));
+    if (row_b) HIP_TRY(h, hipMemcpy(row_b, h->P.row_b, n, hipMemcpyDeviceToHost));
+    if (col_b) HIP_TRY(h, hipMemcpy(col_b, h->P.col_b, n, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(h, hipMemcpy(t, h->P.t, n, hipMemcpyDeviceToHost));
+    if (poss || needs_reset) {
+        std::vector<uint8_t> ps(n);
+        HIP_TRY(h, hipMemcpy(ps.data(), h->P.poss, n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            if (poss) poss[i] = ps[i] & 1;
+            if (needs_reset) needs_reset[i] = (ps[i] >> 1) & 1;
+        }
+    }
+    return SOCCER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int soccer_dims(const soccer_handle* h, int32_t* n_states, int32_t* lut_len, int32_t* n_isd,
+                           int32_t* internal_width) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (n_states) *n_states = h->rules.nS;
+    if (lut_len) *lut_len = static_cast<int32_t>(h->rules.lut.size());
+    if (n_isd) *n_isd = h->rules.n_isd;
+    if (internal_width) *internal_width = h->rules.W;
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_get_tables(const soccer_handle* h, uint16_t* lut, int8_t* goal_value, int8_t* isd_states) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    const Rules& R = h->rules;
+    if (lut) std::memcpy(lut, R.lut.data(), R.lut.size() * sizeof(uint16_t));
+    if (goal_value) std::memcpy(goal_value, R.goal_value.data(), R.goal_value.size());
+    if (isd_states) for (int i = 0; i < R.n_isd; ++i) for (int k = 0; k < 5; ++k) isd_states[i * 5 + k] = R.isd[i][k];
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_prob_table(const soccer_handle* h, double prob[12]) {
+    if (!h || !prob) return fail(nullptr, SOCCER_E_INVALID, "handle/prob is NULL");
+    static const double nsp[3] = {1.0, 0.5, 0.25};
+    for (int c = 0; c < 4; ++c) for (int k = 0; k < 3; ++k) prob[c * 3 + k] = h->P.w[c] * nsp[k];   // :241
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* misuse) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_get_stats during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (hist) {
+        std::vector<unsigned long long> shards(kHistShards * kHistStride);
+        HIP_TRY(h, hipMemcpy(shards.data(), h->d_hist, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        hist[0] = hist[1] = hist[2] = 0;
+        for (int s = 0; s < kHistShards; ++s) for (int b = 0; b < 3; ++b) hist[b] += shards[s * kHistStride + b];
+    }
+    if (misuse) {
+        unsigned int m = 0;
+        HIP_TRY(h, hipMemcpy(&m, h->d_misuse, sizeof m, hipMemcpyDeviceToHost));
+        *misuse = m;
+    }
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_reset_stats(soccer_handle* h) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemsetAsync(h->d_hist, 0, sizeof(unsigned long long) * kHistShards * kHistStride, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_misuse, 0, 128, h->stream));
+    return SOCCER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int soccer_malloc(soccer_handle* h, size_t bytes, void** dptr) {
+    if (!h || !dptr) return fail(h, SOCCER_E_INVALID, "handle/dptr is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMalloc(dptr, bytes ? bytes : 1));
+    return SOCCER_OK;
+}
+extern "C" int soccer_free(soccer_handle* h, void* dptr) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (dptr) HIP_TRY(h, hipFree(dptr));
+    return SOCCER_OK;
+}
+extern "C" int soccer_memcpy_h2d(soccer_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_memcpy_h2d during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SOCCER_OK;
+}
+extern "C" int soccer_memcpy_d2h(soccer_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_memcpy_d2h during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SOCCER_OK;
+}
+extern "C" int soccer_memset(soccer_handle* h, void* dst, int value, size_t bytes) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemsetAsync(dst, value, bytes, h->stream));
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_timer_start(soccer_handle* h) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    return SOCCER_OK;
+}
+extern "C" int soccer_timer_stop(soccer_handle* h, float* elapsed_ms) {
+    if (!h || !elapsed_ms) return fail(h, SOCCER_E_INVALID, "handle/elapsed_ms is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return SOCCER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int soccer_graph_begin(soccer_handle* h) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "graph capture already in progress");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true; h->capture_ticks = 0; h->capture_calls = 0;
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_graph_end(soccer_handle* h, soccer_graph** out) {
+    if (!h || !out) return fail(h, SOCCER_E_INVALID, "handle/out is NULL");
+    if (!h->capturing) return fail(h, SOCCER_E_STATE, "no graph capture in progress");
+    h->capturing = false;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
+    if (h->capture_calls % 2 != 0) {
+        // an odd count would leave the tick in the other slot after a replay
+        h->tick_slot ^= 1;
+        (void)hipGraphDestroy(graph);
+        return fail(h, SOCCER_E_INVALID, "a captured sequence must contain an even number of batched_* calls (got %d)",
+                    h->capture_calls);
+    }
+    soccer_graph* g = new soccer_graph();
+    g->graph = graph; g->ticks = h->capture_ticks;
+    hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph); delete g;
+        return fail(h, SOCCER_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    *out = g;
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t replays) {
+    if (!h || !g) return fail(h, SOCCER_E_INVALID, "handle/graph is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_graph_launch during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int32_t r = 0; r < replays; ++r) HIP_TRY(h, hipGraphLaunch(g->exec, h->stream));
+    h->tick += g->ticks * (uint64_t)(replays > 0 ? replays : 0);
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_graph_destroy(soccer_handle* h, soccer_graph* g) {
+    if (!g) return SOCCER_OK;
+    if (h) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->stream); }
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return SOCCER_OK;
+}

@@ -86,7 +86,7 @@ typedef struct soccer_config {
     uint64_t seed;          /* Philox key */
     uint64_t lane_offset;   /* global id of lane 0 (multi-GPU sharding) */
     uint32_t flags;         /* SOCCER_F_* */
-    uint32_t envs_per_thread; /* 0 = library default; 1,4,8,16 force a vector width */
+    uint32_t envs_per_thread; /* 0 = library default; 1, 4 or 8 force a vector width */
     void*    stream;        /* hipStream_t to enqueue on, or NULL: the handle creates its own */
 } soccer_config;
 
@@ -102,6 +102,8 @@ typedef struct soccer_step_args {
     uint8_t*       truncated;   /* [n] timestep >= max_steps (:404) */
     uint8_t*       prob_code;   /* [n] code of the sampled transition's probability, see soccer_prob_table */
     uint16_t*      final_obs;   /* [n] observation BEFORE auto-reset (equals obs when none fired) */
+    int8_t*        last_return; /* [n] A's return of the lane's most recently finished episode; written
+                                   only on the step an episode ends (terminated or truncated) */
 } soccer_step_args;
 
 /* batched_rollout arguments: T fused steps with state held in registers.
@@ -172,8 +174,8 @@ int soccer_prob_table(const soccer_handle* h, double prob[12]);
 
 /* ---- episode statistics ------------------------------------------------------------------ */
 /* hist[0..2] = episodes finished with A's return -1, 0, +1 since create / soccer_reset_stats;
- * misuse = lane-steps attempted on lanes that needed reset (the reference's assert, :376).
- * Synchronises the stream. HOST outputs. */
+ * misuse = nonzero if any lane was stepped while it needed reset (the reference's assert, :376;
+ * such lanes are left untouched).  Synchronises the stream. HOST outputs. */
 int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* misuse);
 int soccer_reset_stats(soccer_handle* h);
 uint64_t soccer_tick(const soccer_handle* h);

@@ -92,6 +92,10 @@ class Oracle:
         self.t = np.zeros(self.n, np.uint8)
         self.hist = np.zeros(3, np.uint64)
         self.misuse = 0
+        # like the product, lanes are parked on the first ISD tuple until the first reset
+        isd0 = self.tables()[3][0]
+        self.row_a[:] = isd0[0]; self.col_a[:] = isd0[1]; self.row_b[:] = isd0[2]; self.col_b[:] = isd0[3]
+        self.poss[:] = 2 | int(isd0[4])
 
     def __del__(self):
         try:

@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI boundary: the library loads and exports every symbol that
+include/soccer_hip.h declares, and argument validation (the reference's asserts) happens before
+any device work.  No compute calls here — those are the -m gpu tests."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from gym_soccer_littman94_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "soccer_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:soccer|batched)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), "libsoccer_hip.so does not export %s" % name
+    assert sorted(_lib.PROTOTYPES) == declared, "ctypes prototypes and header disagree"
+    assert lib.soccer_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives these structs on x86-64 (checked against the header by field count)
+    assert C.sizeof(_lib.Config) == 64
+    assert C.sizeof(_lib.StepArgs) == 11 * 8
+    assert C.sizeof(_lib.RolloutArgs) == 8 + 2 * 8 + 8 + 4 * 8 + 8 + 2 * 8
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(width=4), "Width must be at least 5"),
+    (dict(height=3), "Height must be at least 4"),
+    (dict(slip_prob=1.5), "slip_prob"),
+    (dict(n_lanes=0), "n_lanes"),
+    (dict(max_steps=0), "max_steps"),
+    (dict(envs_per_thread=3), "envs_per_thread"),
+])
+def test_create_rejects_bad_config_like_the_reference_asserts(kw, msg):
+    lib = _lib.load()
+    base = dict(n_lanes=8, width=5, height=4, slip_prob=0.0, max_steps=100, device=0, seed=0,
+                lane_offset=0, flags=0, envs_per_thread=0, stream=None)
+    base.update(kw)
+    cfg = _lib.Config(**base)
+    h = C.c_void_p()
+    code = lib.soccer_create(C.byref(cfg), C.byref(h))
+    assert code == _lib.E_INVALID and not h.value
+    with pytest.raises(AssertionError, match=msg):
+        _lib.check(lib, None, code)
+
+
+def test_no_cpu_fallback_without_a_device():
+    """On a box without a GPU the product must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gym_soccer_littman94_amd import SoccerBatch
+    with pytest.raises(_lib.SoccerHipError, match="no CPU path|no HIP device|failed"):
+        SoccerBatch(16)

@@ -1,0 +1,322 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bar: bit-exact — every lane, every step: state, observation, reward, terminated, truncated,
+probability code (integer / byte work; the only floating point is the float64 running-sum
+comparison of the slip lists, which must select the same index as the reference does).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from gym_soccer_littman94_amd import SoccerBatch
+from oracle.oracle import Oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TABLES = sorted(glob.glob(os.path.join(GOLDEN, "table_*.npz")))
+REPLAYS = sorted(glob.glob(os.path.join(GOLDEN, "replay_*.npz")))
+RESETS = sorted(glob.glob(os.path.join(GOLDEN, "reset_*.npz")))
+TRAJS = sorted(glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
+
+
+def _ids(paths):
+    return [os.path.basename(p)[:-4] for p in paths]
+
+
+class Bufs:
+    """Device I/O buffers for one SoccerBatch."""
+    def __init__(self, b, with_u=False):
+        n = b.n
+        self.b = b
+        self.act_a = b.alloc(n, np.int8); self.act_b = b.alloc(n, np.int8)
+        self.obs = b.alloc(n, np.uint16); self.reward = b.alloc(n, np.int8)
+        self.term = b.alloc(n, np.uint8); self.trunc = b.alloc(n, np.uint8)
+        self.code = b.alloc(n, np.uint8); self.fin = b.alloc(n, np.uint16)
+        self.last = b.alloc(n, np.int8).fill(0)
+        self.u_step = b.alloc(n, np.float64) if with_u else None
+        self.u_reset = b.alloc(n, np.float64) if with_u else None
+
+    def step(self, a, bb, u_step=None, u_reset=None):
+        self.act_a.upload(a); self.act_b.upload(bb)
+        if u_step is not None: self.u_step.upload(u_step)
+        if u_reset is not None: self.u_reset.upload(u_reset)
+        self.b.step(self.act_a, self.act_b, obs=self.obs, reward=self.reward, terminated=self.term,
+                    truncated=self.trunc, prob_code=self.code, final_obs=self.fin, last_return=self.last,
+                    u_step=self.u_step if u_step is not None else None,
+                    u_reset=self.u_reset if u_reset is not None else None)
+        return dict(obs=self.obs.download(), reward=self.reward.download(), terminated=self.term.download(),
+                    truncated=self.trunc.download(), prob_code=self.code.download(), final_obs=self.fin.download())
+
+
+def assert_state_equal(b, o):
+    s = b.get_state()
+    np.testing.assert_array_equal(s["row_a"], o.row_a); np.testing.assert_array_equal(s["col_a"], o.col_a)
+    np.testing.assert_array_equal(s["row_b"], o.row_b); np.testing.assert_array_equal(s["col_b"], o.col_b)
+    np.testing.assert_array_equal(s["poss"], o.poss & 1)
+    np.testing.assert_array_equal(s["needs_reset"], (o.poss >> 1) & 1)
+    np.testing.assert_array_equal(s["t"], o.t)
+
+
+def assert_out_equal(g, c):
+    for k in ("obs", "reward", "terminated", "truncated", "prob_code", "final_obs"):
+        np.testing.assert_array_equal(g[k], c[k], err_msg=k)
+
+
+@pytest.mark.parametrize("path", TABLES, ids=_ids(TABLES))
+def test_rule_tables_match_reference(path):
+    g = np.load(path)
+    b = SoccerBatch(4, int(g["width"]), int(g["height"]), float(g["slip"]))
+    lut, gv, isd = b.tables()
+    assert b.nS == int(g["nS"])
+    np.testing.assert_array_equal(lut, g["lut"])
+    np.testing.assert_array_equal(gv, g["goal_value"])
+    np.testing.assert_array_equal(isd, g["isd_states"])
+    # slip weights * outcome probabilities exactly as the reference computes them (float64)
+    probs = set(np.unique(g["prob"]).tolist())
+    assert probs <= set(b.prob_table.tolist()), (probs, b.prob_table)
+    b.close()
+
+
+@pytest.mark.parametrize("epw", [1, 4, 8])
+@pytest.mark.parametrize("path", REPLAYS, ids=_ids(REPLAYS))
+def test_replay_vectors_from_reference_step(path, epw):
+    """(state, t, joint action, u) vectors that were pushed through the REAL reference step()."""
+    g = np.load(path)
+    n = len(g["u"])
+    b = SoccerBatch(n, int(g["width"]), int(g["height"]), float(g["slip"]), envs_per_thread=epw)
+    st = g["state"]
+    b.set_state(st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], t=g["t"], needs_reset=0)
+    io = Bufs(b, with_u=True)
+    out = io.step(g["action"][:, 0], g["action"][:, 1], u_step=g["u"], u_reset=np.zeros(n))
+    s = b.get_state(); ns = g["next_state"]
+    np.testing.assert_array_equal(s["row_a"], ns[:, 0]); np.testing.assert_array_equal(s["col_a"], ns[:, 1])
+    np.testing.assert_array_equal(s["row_b"], ns[:, 2]); np.testing.assert_array_equal(s["col_b"], ns[:, 3])
+    np.testing.assert_array_equal(s["poss"], ns[:, 4])
+    np.testing.assert_array_equal(s["needs_reset"], g["needs_reset"])
+    np.testing.assert_array_equal(out["obs"], g["obs"])
+    np.testing.assert_array_equal(out["reward"].astype(np.float64), g["reward_a"])
+    np.testing.assert_array_equal(out["terminated"], g["terminated"])
+    np.testing.assert_array_equal(out["truncated"], g["truncated"])
+    np.testing.assert_array_equal(np.round(b.prob_table[out["prob_code"]], 2), g["p"])
+    assert b.stats()[1] == 0
+    b.close()
+
+
+@pytest.mark.parametrize("path", RESETS, ids=_ids(RESETS))
+def test_reset_vectors_from_reference_reset(path):
+    g = np.load(path)
+    n = len(g["u"])
+    b = SoccerBatch(n, int(g["width"]), int(g["height"]), 0.0)
+    u = b.alloc(n, np.float64).upload(g["u"]); obs = b.alloc(n, np.uint16)
+    b.reset(u_reset=u, obs=obs)
+    s = b.get_state(); st = g["state"]
+    np.testing.assert_array_equal(obs.download(), g["obs"])
+    for k, c in (("row_a", 0), ("col_a", 1), ("row_b", 2), ("col_b", 3), ("poss", 4)):
+        np.testing.assert_array_equal(s[k], st[:, c])
+    assert not s["t"].any() and not s["needs_reset"].any()
+    b.close()
+
+
+@pytest.mark.parametrize("path", TRAJS, ids=_ids(TRAJS))
+def test_mt19937_trajectories_lane_parallel(path):
+    """Every step of the reference's MT19937-driven episodes, one lane per recorded step:
+    lane k is put in the state the reference was in before its step k and fed the uniform the
+    reference drew there (and, where the reference called reset() first, the reset uniform)."""
+    g = np.load(path)
+    n = len(g["obs"])
+    reset_mask = g["reset_before"].copy(); reset_mask[0] = 1
+    u_r = np.where(g["reset_before"] == 1, g["u_reset"], 0.0); u_r[0] = g["u_first_reset"]
+    t_before = np.zeros(n, np.uint8); c = 0
+    for k in range(n):
+        if reset_mask[k]:
+            c = 0
+        t_before[k] = c; c += 1
+    prev = np.vstack([np.array([[1, 2, 2, 4, 0]], np.int8), g["state"][:-1]])
+    keep = reset_mask == 0          # lanes the reference did not reset start from its previous state
+    park = np.array([1, 2, 2, 4, 0], np.int8)
+    init = np.where(keep[:, None], prev, park[None, :])
+    b = SoccerBatch(n, 5, 4, float(g["slip"]))
+    b.set_state(init[:, 0], init[:, 1], init[:, 2], init[:, 3], init[:, 4], t=t_before, needs_reset=0)
+    m = b.alloc(n, np.uint8).upload(reset_mask); u = b.alloc(n, np.float64).upload(u_r)
+    obs0 = b.alloc(n, np.uint16)
+    b.reset(mask=m, u_reset=u, obs=obs0)
+    got0 = obs0.download()
+    assert got0[0] == g["first_obs"]
+    rb = g["reset_before"] == 1
+    np.testing.assert_array_equal(got0[rb], g["reset_obs"][rb])
+    io = Bufs(b, with_u=True)
+    out = io.step(g["actions"][:, 0], g["actions"][:, 1], u_step=g["u_step"], u_reset=np.zeros(n))
+    np.testing.assert_array_equal(out["obs"], g["obs"])
+    np.testing.assert_array_equal(out["reward"].astype(np.float64), g["reward_a"])
+    np.testing.assert_array_equal(out["terminated"], g["terminated"])
+    np.testing.assert_array_equal(out["truncated"], g["truncated"])
+    np.testing.assert_array_equal(np.round(b.prob_table[out["prob_code"]], 2), g["p"])
+    s = b.get_state()
+    got = np.stack([s["row_a"], s["col_a"], s["row_b"], s["col_b"], s["poss"]], 1)
+    np.testing.assert_array_equal(got, g["state"])
+    b.close()
+
+
+@pytest.mark.parametrize("slip,width,height,epw,n", [
+    (0.0, 5, 4, 0, 65536),      # BASELINE config 2
+    (0.2, 5, 4, 0, 65536),
+    (0.0, 5, 4, 8, 65536 + 13), # ragged tail, 8 lanes per thread
+    (0.2, 5, 4, 1, 4099),
+    (0.3, 7, 5, 4, 8191),
+    (1.0, 5, 4, 4, 8192),
+    (0.0, 11, 7, 4, 8192),
+])
+def test_config2_autoreset_every_lane_every_step_vs_oracle(slip, width, height, epw, n):
+    """BASELINE config 2: 65 536 lanes, Philox seed 0, 200 steps (forces truncation at t=100 and
+    auto-reset), actions from default_rng(2024); every lane, every step compared with the oracle."""
+    steps = 200 if n >= 65536 else 120
+    rng = np.random.default_rng(2024)
+    acts = rng.integers(0, 5, size=(steps, 2, n), dtype=np.int8)
+    seed, off = 0, 12345678901
+    b = SoccerBatch(n, width, height, slip, seed=seed, autoreset=True, lane_offset=off, envs_per_thread=epw)
+    o = Oracle(width, height, slip, n=n, seed=seed, lane_offset=off, autoreset=True)
+    obs = b.alloc(n, np.uint16)
+    b.reset(obs=obs)
+    np.testing.assert_array_equal(obs.download(), o.reset())
+    assert_state_equal(b, o)
+    io = Bufs(b)
+    last = np.zeros(n, np.int8)
+    for k in range(steps):
+        g = io.step(acts[k, 0], acts[k, 1])
+        c = o.step(acts[k, 0], acts[k, 1])
+        assert_out_equal(g, c)
+        fin = (c["terminated"] | c["truncated"]) == 1
+        last[fin] = c["reward"][fin]
+        if k % 25 == 0 or k == steps - 1:
+            assert_state_equal(b, o)
+    np.testing.assert_array_equal(io.last.download(), last)
+    hist, misuse = b.stats()
+    np.testing.assert_array_equal(hist, o.hist)
+    assert misuse == 0 and b.tick == o.tick == steps + 1
+    assert hist.sum() > n          # at least one full episode per lane on average
+    b.close()
+
+
+def test_no_autoreset_freezes_finished_lanes_and_flags_misuse():
+    n = 4096
+    rng = np.random.default_rng(7)
+    b = SoccerBatch(n, 5, 4, 0.2, seed=3, autoreset=False)
+    o = Oracle(5, 4, 0.2, n=n, seed=3, autoreset=False)
+    # stepping before reset: every lane needs reset (reference: AssertionError at :376)
+    io = Bufs(b)
+    a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+    assert_out_equal(io.step(a[0], a[1]), o.step(a[0], a[1]))
+    assert b.stats()[1] == 1 and o.misuse == n
+    b.reset_stats(); o.misuse = 0
+    obs = b.alloc(n, np.uint16); b.reset(obs=obs)
+    np.testing.assert_array_equal(obs.download(), o.reset())
+    for k in range(130):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        assert_out_equal(io.step(a[0], a[1]), o.step(a[0], a[1]))
+    assert_state_equal(b, o)
+    s = b.get_state()
+    assert s["needs_reset"].all()          # everyone terminated or hit t=100 by now
+    assert b.stats()[1] == 1
+    # masked reset brings back only the selected lanes
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    m = b.alloc(n, np.uint8).upload(mask)
+    b.reset(mask=m, obs=obs)
+    np.testing.assert_array_equal(obs.download(), o.reset(mask=mask))
+    assert_state_equal(b, o)
+    b.close()
+
+
+def test_rollout_equals_successive_steps_and_sampled_actions_match_oracle():
+    n, T = 32768 + 5, 64
+    rng = np.random.default_rng(11)
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    for slip in (0.0, 0.2):
+        b = SoccerBatch(n, 5, 4, slip, seed=99, autoreset=True)
+        o = Oracle(5, 4, slip, n=n, seed=99, autoreset=True)
+        b.reset(); o.reset()
+        A = b.alloc((T, n), np.int8).upload(acts[:, 0]); B = b.alloc((T, n), np.int8).upload(acts[:, 1])
+        obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8)
+        term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
+        rs = b.alloc(n, np.int32).fill(0); ec = b.alloc(n, np.int32).fill(0)
+        b.rollout(T, A, B, act_stride=n, obs=obs, reward=rew, terminated=term, truncated=trunc,
+                  out_stride=n, return_sum=rs, episode_count=ec)
+        O, R, TE, TR = obs.download(), rew.download(), term.download(), trunc.download()
+        ret = np.zeros(n, np.int64); eps = np.zeros(n, np.int64)
+        for k in range(T):
+            c = o.step(acts[k, 0], acts[k, 1])
+            np.testing.assert_array_equal(O[k], c["obs"]); np.testing.assert_array_equal(R[k], c["reward"])
+            np.testing.assert_array_equal(TE[k], c["terminated"]); np.testing.assert_array_equal(TR[k], c["truncated"])
+            ret += c["reward"]; eps += (c["terminated"] | c["truncated"])
+        assert_state_equal(b, o)
+        np.testing.assert_array_equal(rs.download(), ret); np.testing.assert_array_equal(ec.download(), eps)
+        np.testing.assert_array_equal(b.stats()[0], o.hist)
+        # in-kernel uniform-random actions (BASELINE config 5 shape): same Philox stream in the oracle
+        b.rollout(T, sample_actions=True, return_sum=rs, episode_count=ec)
+        for k in range(T):
+            a, bb = o.sample_actions()
+            c = o.step(a, bb)
+            ret += c["reward"]; eps += (c["terminated"] | c["truncated"])
+        assert_state_equal(b, o)
+        np.testing.assert_array_equal(rs.download(), ret); np.testing.assert_array_equal(ec.download(), eps)
+        np.testing.assert_array_equal(b.stats()[0], o.hist)
+        assert b.tick == o.tick
+        b.close()
+
+
+def test_results_do_not_depend_on_sharding_or_vector_width():
+    """Lanes [0,N) on one handle == two handles of N/2 with lane_offset (multi-GPU contract)."""
+    n, T = 16384, 40
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    def run(lo, hi, epw):
+        b = SoccerBatch(hi - lo, 5, 4, 0.2, seed=42, autoreset=True, lane_offset=lo, envs_per_thread=epw)
+        b.reset(); io = Bufs(b); outs = []
+        for k in range(T):
+            outs.append(io.step(acts[k, 0, lo:hi], acts[k, 1, lo:hi])["obs"])
+        h = b.stats()[0]; b.close()
+        return np.stack(outs), h
+    full, hf = run(0, n, 4)
+    a, ha = run(0, n // 2, 8); c, hc = run(n // 2, n, 1)
+    np.testing.assert_array_equal(full, np.concatenate([a, c], 1))
+    np.testing.assert_array_equal(hf, ha + hc)
+
+
+def test_graph_capture_replays_advance_the_tick():
+    n, T = 8192, 6
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    b = SoccerBatch(n, 5, 4, 0.0, seed=1, autoreset=True)
+    o = Oracle(5, 4, 0.0, n=n, seed=1, autoreset=True)
+    b.reset(); o.reset()
+    A = b.alloc((T, n), np.int8).upload(acts[:, 0]); B = b.alloc((T, n), np.int8).upload(acts[:, 1])
+    obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8)
+    term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
+    b.graph_begin()
+    for k in range(T):
+        b.step_plain(A.row(k), B.row(k), obs.row(k), rew.row(k), term.row(k), trunc.row(k))
+    g = b.graph_end()
+    for rep in range(3):
+        b.graph_launch(g, 1)
+        O, R = obs.download(), rew.download()
+        for k in range(T):
+            c = o.step(acts[k, 0], acts[k, 1])
+            np.testing.assert_array_equal(O[k], c["obs"]); np.testing.assert_array_equal(R[k], c["reward"])
+    assert b.tick == o.tick == 1 + 3 * T
+    assert_state_equal(b, o)
+    b.graph_destroy(g)
+    with pytest.raises(AssertionError, match="even number"):
+        b.graph_begin(); b.step_plain(A.row(0), B.row(0), obs.row(0), rew.row(0), term.row(0), trunc.row(0))
+        b.graph_end()
+    b.close()
+
+
+def test_state_injection_rejects_unreachable_tuples():
+    b = SoccerBatch(2, 5, 4, 0.0)
+    with pytest.raises(KeyError):
+        b.set_state([1, 1], [1, 1], [1, 2], [1, 2], [0, 0], t=0, needs_reset=0)   # both players in one cell
+    with pytest.raises(KeyError):
+        b.set_state([0, 1], [0, 1], [1, 2], [3, 3], [0, 0], t=0, needs_reset=0)   # corner of a goal column
+    b.close()
