@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched Littman-94 soccer step on MI355X.
+
+Workload (BASELINE.json metric / configs[2]): 1 048 576 environments per
+GPU, uniform-random joint actions resident in HBM, auto-reset on terminal/truncation, int8 SoA
+state.  One "step" = one batched_step launch over the whole batch through the C ABI
+(libsoccer_hip.so).  With --gpus N each rank owns its own contiguous shard of N x 2^20 global
+lanes (weak scaling; no collective on the data path; one RCCL all_gather of the int8 per-lane
+episode returns after the timed region — BASELINE configs[3]).
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = 19 algorithmic bytes per env-step (SURVEY.md
+§8(d): read 6 B state + 2 B actions, write 6 B state + 5 B obs/reward/terminated/truncated) x lanes
+per launch / the average launch duration measured with HIP events on the kernel's own stream.
+`cpu_baseline` = the CPU oracle (oracle/soccer_oracle.c, a port pinned bit-for-bit to the reference
+by tests/golden) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 19
+HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(lanes_total, slip, seconds):
+    """The oracle on the host cores: one Oracle per thread, each over its own lane shard."""
+    from oracle.oracle import Oracle
+    cores = len(os.sched_getaffinity(0))
+    threads = max(1, min(cores, 64))
+    per = 16384
+    rng = np.random.default_rng(2024)
+    acts = rng.integers(0, 5, size=(64, 2, per), dtype=np.int8)
+    oracles = [Oracle(5, 4, slip, n=per, seed=0, lane_offset=i * per, autoreset=True) for i in range(threads)]
+    for o in oracles:
+        o.reset()
+    counts = [0] * threads
+    deadline = [0.0]
+
+    def work(i):
+        o, k = oracles[i], 0
+        while time.perf_counter() < deadline[0]:
+            o.step(acts[k % 64, 0], acts[k % 64, 1]); k += 1
+        counts[i] = k
+    # calibrate on one thread for ~1 s so the sample is bounded, then run all threads
+    deadline[0] = time.perf_counter() + seconds
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    dt = time.perf_counter() - t0
+    steps = sum(counts) * per
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d threads x %d lanes x ~%d steps of the same uniform-random workload (%.1f s)"
+                      % (threads, per, counts[0], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--lanes", type=int, default=1 << 20, help="environments per GPU")
+    ap.add_argument("--slip", type=float, default=0.0)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--envs-per-thread", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout", type=int, default=100, help="also time a fused T-step rollout (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to bench)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from gym_soccer_littman94_amd import SoccerBatch
+    N, K, W = args.lanes, args.steps, args.warmup
+    K += K % 2                                   # a captured sequence holds an even number of launches
+    b = SoccerBatch(N, 5, 4, args.slip, seed=0, autoreset=True, device=local_rank,
+                    lane_offset=rank * N, envs_per_thread=args.envs_per_thread)
+
+    # synthetic inputs, resident in HBM before the timed region: uniform-random joint actions for
+    # every step; outputs stream into [K, N] trajectory buffers (nothing is cached or skipped)
+    g = torch.Generator(device=dev); g.manual_seed(2024 + rank)
+    KA = max(K, W)
+    acts = torch.randint(0, 5, (KA, 2, N), dtype=torch.int8, device=dev, generator=g)
+    obs = torch.empty((K, N), dtype=torch.int16, device=dev)
+    rew = torch.empty((K, N), dtype=torch.int8, device=dev)
+    term = torch.empty((K, N), dtype=torch.uint8, device=dev)
+    trunc = torch.empty((K, N), dtype=torch.uint8, device=dev)
+    last_ret = torch.zeros((N,), dtype=torch.int8, device=dev)
+    torch.cuda.synchronize()
+
+    def enqueue(k):
+        b.step(acts[k, 0], acts[k, 1], obs=obs[k], reward=rew[k], terminated=term[k], truncated=trunc[k],
+               last_return=last_ret)
+
+    b.reset()
+    for k in range(W):
+        enqueue(k % K)
+    b.sync()
+    graph = None
+    if args.mode == "graph":
+        b.graph_begin()
+        for k in range(K):
+            enqueue(k)
+        graph = b.graph_end()
+    b.reset_stats()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        b.sync(); torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    b.timer_start()
+    if graph is not None:
+        b.graph_launch(graph, 1)
+    else:
+        for k in range(K):
+            enqueue(k)
+    ev_ms = b.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(tt[0]), float(tt[1])
+
+    # ---- after the timed region: aggregate episode returns (the only cross-GPU exchange) -------
+    hist, misuse = b.stats()
+    assert misuse == 0
+    gathered = None
+    if world > 1:
+        parts = [torch.empty_like(last_ret) for _ in range(world)]
+        dist.all_gather(parts, last_ret)            # RCCL over xGMI, int8[N] per rank
+        gathered = torch.cat(parts)
+        h = torch.tensor(hist.astype(np.int64), device=dev)
+        dist.all_reduce(h)
+        hist = h.cpu().numpy()
+    else:
+        gathered = last_ret
+    # cheap end-to-end sanity on the real outputs of the timed steps (not a parity test)
+    fin = ((term | trunc) != 0)
+    n_fin = int(fin.sum()); r_sum = int(rew.to(torch.int32).sum())
+    assert 0 < n_fin < K * N and abs(r_sum) < n_fin, "implausible outputs"
+    assert int(obs.max()) < b.nS and int(rew.abs().max()) == 1
+
+    # ---- optional: fused T-step rollout (state in registers, same per-step results) -------------
+    rollout = None
+    if args.rollout > 0:
+        T = min(args.rollout, K)
+        b.rollout(T, acts[0, 0], acts[0, 1], act_stride=2 * N, obs=obs, reward=rew, terminated=term,
+                  truncated=trunc, out_stride=N)          # warm
+        barrier()
+        b.timer_start()
+        b.rollout(T, acts[0, 0], acts[0, 1], act_stride=2 * N, obs=obs, reward=rew, terminated=term,
+                  truncated=trunc, out_stride=N)
+        r_ms = b.timer_stop()
+        if world > 1:
+            tt = torch.tensor([r_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX); r_ms = float(tt[0])
+        bytes_per = 7 + 12.0 / T                         # 2 B actions in, 5 B out, state amortised over T
+        rollout = {"steps_fused": T, "env_steps_per_s": world * N * T / (r_ms * 1e-3),
+                   "bytes_per_env_step": bytes_per,
+                   "achieved_GBps": bytes_per * N * T / (r_ms * 1e-3) / 1e9}
+
+    if rank == 0:
+        launch_s = ev_ms * 1e-3 / K
+        achieved = ALGO_BYTES_PER_ENV_STEP * N / launch_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")   # from a separate rocprofv3 --pmc run
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("step_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node) at batch=1M random joint actions; HBM GB/s vs peak",
+            "value": world * N * K / wall, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": {"workload": "%d envs/GPU x %d GPU(s), SoccerSimultaneous 5x4, slip_prob=%g, "
+                                   "uniform-random joint actions, auto-reset, int8 SoA state, %s launches"
+                                   % (N, world, args.slip, args.mode),
+                       "lanes_per_gpu": N, "global_lanes": world * N, "slip_prob": args.slip,
+                       "parallelism": "independent lane shards x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "step_kernel", "launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
+            "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
+                         "gathered_last_returns": int(gathered.numel()),
+                         "gathered_mean": float(gathered.to(torch.float32).mean())},
+        }
+        if rollout:
+            out["fused_rollout"] = rollout
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, args.slip, args.cpu_seconds)
+        print(json.dumps(out))
+    if graph is not None:
+        b.graph_destroy(graph)
+    b.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,7 @@ struct soccer_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t ticks = 0;       // ticks consumed by one replay
+    int start_slot = 0;       // tick slot the first captured launch reads
 };
 
 struct soccer_handle {
@@ -46,6 +47,7 @@ struct soccer_handle {
     bool capturing = false;
     uint64_t capture_ticks = 0;
     int capture_calls = 0;
+    int capture_start_slot = 0;
     std::string err;
 };
 
@@ -563,6 +565,7 @@ extern "C" int soccer_graph_begin(soccer_handle* h) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->capturing = true; h->capture_ticks = 0; h->capture_calls = 0;
+    h->capture_start_slot = h->tick_slot;
     return SOCCER_OK;
 }
 
@@ -580,7 +583,7 @@ extern "C" int soccer_graph_end(soccer_handle* h, soccer_graph** out) {
                     h->capture_calls);
     }
     soccer_graph* g = new soccer_graph();
-    g->graph = graph; g->ticks = h->capture_ticks;
+    g->graph = graph; g->ticks = h->capture_ticks; g->start_slot = h->capture_start_slot;
     hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(graph); delete g;
@@ -594,6 +597,12 @@ extern "C" int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t re
     if (!h || !g) return fail(h, SOCCER_E_INVALID, "handle/graph is NULL");
     if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_graph_launch during graph capture");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (replays > 0 && h->tick_slot != g->start_slot) {
+        // launches issued since the capture left the tick in the other slot: move it across
+        HIP_TRY(h, hipMemcpyAsync(h->d_tick + (g->start_slot ? 16 : 0), h->d_tick + (h->tick_slot ? 16 : 0),
+                                  sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+        h->tick_slot = g->start_slot;
+    }
     for (int32_t r = 0; r < replays; ++r) HIP_TRY(h, hipGraphLaunch(g->exec, h->stream));
     h->tick += g->ticks * (uint64_t)(replays > 0 ? replays : 0);
     return SOCCER_OK;
