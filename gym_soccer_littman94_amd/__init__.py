@@ -4,5 +4,9 @@ Host side: Python mirroring the reference's SoccerSimultaneousEnv surface; devic
 HIP kernels for gfx950 behind a C ABI (libsoccer_hip.so, include/soccer_hip.h).
 """
 from .core import DeviceArray, SoccerBatch  # noqa: F401
+from .envs import SoccerSimultaneousEnv, VectorSoccerEnv  # noqa: F401
+from .registration import make, register_all  # noqa: F401
 
-__all__ = ["SoccerBatch", "DeviceArray"]
+register_all()
+
+__all__ = ["SoccerBatch", "DeviceArray", "SoccerSimultaneousEnv", "VectorSoccerEnv", "make", "register_all"]

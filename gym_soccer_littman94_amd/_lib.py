@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libsoccer_hip.so")
 
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE = 0, -1, -2, -3, -4
 F_AUTORESET = 1
+F_NULL_STREAM = 2
 
 
 class SoccerHipError(RuntimeError):
@@ -51,6 +52,8 @@ PROTOTYPES = {
     "batched_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "batched_step_ex": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
     "batched_rollout": (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs)]),
+    "batched_step_host": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
+    "batched_reset_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "soccer_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "soccer_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "soccer_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
@@ -75,6 +78,31 @@ PROTOTYPES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and HSA runtime.
+    Two HIP runtimes in one process cannot both open the GPU, so when torch is installed make sure
+    the copy torch will use is the one already in the process before libsoccer_hip.so asks for
+    libamdhip64.so.7: the loader then resolves both to the same runtime, and device pointers,
+    streams and events are interchangeable between torch and this library.
+    Set SOCCER_HIP_RUNTIME=system to skip (standalone use without torch)."""
+    import importlib.util
+    import sys
+    if os.environ.get("SOCCER_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libsoccer_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
     global _lib
@@ -84,6 +112,7 @@ def load():
                 "libsoccer_hip.so not found at %s — build it with "
                 "`make -C gym_soccer_littman94_amd/csrc` (or __graft_entry__.build()). "
                 "There is no CPU fallback for the batched step/reset path." % LIB_PATH)
+        _share_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing

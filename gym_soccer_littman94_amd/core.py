@@ -81,13 +81,15 @@ class SoccerBatch:
 
     def __init__(self, n_lanes, width=5, height=4, slip_prob=0.0, seed=0, autoreset=False,
                  max_steps=100, device=0, lane_offset=0, stream=None, envs_per_thread=0):
+        """stream: None -> the handle creates its own HIP stream; an integer hipStream_t -> enqueue on
+        that stream (0 = the device's default/null stream, which is what torch's default stream is)."""
         self.lib = _lib.load()
         self.h = None
         cfg = Config(n_lanes=int(n_lanes), width=int(width), height=int(height),
                      slip_prob=float(slip_prob), max_steps=int(max_steps), device=int(device),
                      seed=int(seed) & 0xFFFFFFFFFFFFFFFF, lane_offset=int(lane_offset),
-                     flags=_lib.F_AUTORESET if autoreset else 0,
-                     envs_per_thread=int(envs_per_thread), stream=stream)
+                     flags=(_lib.F_AUTORESET if autoreset else 0) | (_lib.F_NULL_STREAM if stream == 0 else 0),
+                     envs_per_thread=int(envs_per_thread), stream=stream or None)
         h = C.c_void_p()
         _lib.check(self.lib, None, self.lib.soccer_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -161,6 +163,32 @@ class SoccerBatch:
                         _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated), int(out_stride),
                         _ptr(return_sum), _ptr(episode_count))
         self._check(self.lib.batched_rollout(self.h, C.byref(a)))
+
+    # -- host-array variants (numpy in, numpy out; one staged copy each way) -------------------
+    def reset_host(self, mask=None, u_reset=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        u = None if u_reset is None else np.ascontiguousarray(u_reset, np.float64)
+        obs = np.empty(self.n, np.uint16)
+        self._check(self.lib.batched_reset_host(self.h, None if m is None else m.ctypes.data,
+                                                None if u is None else u.ctypes.data, obs.ctypes.data))
+        return obs
+
+    def step_host(self, act_a, act_b, u_step=None, u_reset=None):
+        n = self.n
+        a = np.ascontiguousarray(act_a, np.int8); b = np.ascontiguousarray(act_b, np.int8)
+        assert a.shape == (n,) and b.shape == (n,), "actions must have one entry per environment"
+        us = None if u_step is None else np.ascontiguousarray(u_step, np.float64)
+        ur = None if u_reset is None else np.ascontiguousarray(u_reset, np.float64)
+        out = {"obs": np.empty(n, np.uint16), "reward": np.empty(n, np.int8),
+               "terminated": np.empty(n, np.uint8), "truncated": np.empty(n, np.uint8),
+               "prob_code": np.empty(n, np.uint8), "final_obs": np.empty(n, np.uint16)}
+        args = StepArgs(a.ctypes.data, b.ctypes.data, None if us is None else us.ctypes.data,
+                        None if ur is None else ur.ctypes.data, out["obs"].ctypes.data,
+                        out["reward"].ctypes.data, out["terminated"].ctypes.data,
+                        out["truncated"].ctypes.data, out["prob_code"].ctypes.data,
+                        out["final_obs"].ctypes.data, None)
+        self._check(self.lib.batched_step_host(self.h, C.byref(args)))
+        return out
 
     # -- state injection / readback -----------------------------------------------------------
     def set_state(self, row_a=None, col_a=None, row_b=None, col_b=None, poss=None, t=None, needs_reset=None):

@@ -38,6 +38,11 @@ struct soccer_handle {
     unsigned long long* d_tick = nullptr;   // two slots, 128 B apart
     unsigned long long* d_hist = nullptr;
     unsigned int* d_misuse = nullptr;
+    uint8_t* d_state = nullptr;             // one allocation holding the six SoA streams back to back
+    size_t state_stride = 0;                // bytes between consecutive streams
+    uint8_t* stage_dev = nullptr;           // staging for the host-pointer entry points
+    uint8_t* stage_host = nullptr;          // pinned
+    size_t stage_bytes = 0;
     int tick_slot = 0;                      // slot the NEXT launch reads
     uint64_t tick = 0;                      // host mirror of the device tick
     bool slip = false, lut_lds = true;
@@ -85,10 +90,10 @@ extern "C" const char* soccer_last_error(const soccer_handle* h) { return h ? h-
 static void free_handle(soccer_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->P.row_a, h->P.col_a, h->P.row_b, h->P.col_b, h->P.poss, h->P.t,
-                    h->d_lut, h->d_nc, h->d_tick, h->d_hist, h->d_misuse};
+    (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -145,7 +150,8 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
         }                                                                                         \
     } while (0)
     CREATE_TRY(hipSetDevice(cfg->device));
-    if (cfg->stream) { h->stream = static_cast<hipStream_t>(cfg->stream); h->own_stream = false; }
+    if (cfg->flags & SOCCER_F_NULL_STREAM) { h->stream = nullptr; h->own_stream = false; }
+    else if (cfg->stream) { h->stream = static_cast<hipStream_t>(cfg->stream); h->own_stream = false; }
     else { CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
@@ -153,10 +159,15 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     const Rules& R = h->rules;
     KernelParams& P = h->P;
     const size_t n = cfg->n_lanes;
-    const size_t padded = (n + 63) & ~size_t(63);
-    CREATE_TRY(hipMalloc(&P.row_a, padded)); CREATE_TRY(hipMalloc(&P.col_a, padded));
-    CREATE_TRY(hipMalloc(&P.row_b, padded)); CREATE_TRY(hipMalloc(&P.col_b, padded));
-    CREATE_TRY(hipMalloc(&P.poss, padded));  CREATE_TRY(hipMalloc(&P.t, padded));
+    const size_t padded = (n + 255) & ~size_t(255);
+    h->state_stride = padded;
+    CREATE_TRY(hipMalloc(&h->d_state, 6 * padded));
+    P.row_a = reinterpret_cast<int8_t*>(h->d_state);
+    P.col_a = reinterpret_cast<int8_t*>(h->d_state + padded);
+    P.row_b = reinterpret_cast<int8_t*>(h->d_state + 2 * padded);
+    P.col_b = reinterpret_cast<int8_t*>(h->d_state + 3 * padded);
+    P.poss = h->d_state + 4 * padded;
+    P.t = h->d_state + 5 * padded;
     // every lane starts needing a reset (:140), parked on the first ISD state so the tuple is valid
     CREATE_TRY(hipMemsetAsync(P.row_a, R.isd[0][0], padded, h->stream));
     CREATE_TRY(hipMemsetAsync(P.col_a, R.isd[0][1], padded, h->stream));
@@ -393,17 +404,14 @@ extern "C" int soccer_set_state(soccer_handle* h, const int8_t* row_a, const int
     if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_set_state during graph capture");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const size_t n = h->P.n;
+    const size_t n = h->P.n, S = h->state_stride;
     const Rules& R = h->rules;
     // current device copy of whatever is not supplied, so the resulting tuple can be validated
-    std::vector<int8_t> ra(n), ca(n), rb(n), cb(n);
-    std::vector<uint8_t> ps(n), tt(n);
-    HIP_TRY(h, hipMemcpy(ra.data(), h->P.row_a, n, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(ca.data(), h->P.col_a, n, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(rb.data(), h->P.row_b, n, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(cb.data(), h->P.col_b, n, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(ps.data(), h->P.poss, n, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(tt.data(), h->P.t, n, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> img(6 * S);
+    HIP_TRY(h, hipMemcpy(img.data(), h->d_state, 6 * S, hipMemcpyDeviceToHost));
+    int8_t* ra = reinterpret_cast<int8_t*>(img.data());
+    int8_t* ca = ra + S; int8_t* rb = ra + 2 * S; int8_t* cb = ra + 3 * S;
+    uint8_t* ps = img.data() + 4 * S; uint8_t* tt = img.data() + 5 * S;
     for (size_t i = 0; i < n; ++i) {
         if (row_a) ra[i] = row_a[i];
         if (col_a) ca[i] = col_a[i];
@@ -421,12 +429,7 @@ extern "C" int soccer_set_state(soccer_handle* h, const int8_t* row_a, const int
             return fail(h, SOCCER_E_INVALID, "lane %zu: state (%d, %d, %d, %d, %d) is not a reachable state tuple",
                         i, (int)ra[i], (int)ca[i], (int)rb[i], (int)cb[i], (int)p);
     }
-    HIP_TRY(h, hipMemcpy(h->P.row_a, ra.data(), n, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->P.col_a, ca.data(), n, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->P.row_b, rb.data(), n, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->P.col_b, cb.data(), n, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->P.poss, ps.data(), n, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->P.t, tt.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_state, img.data(), 6 * S, hipMemcpyHostToDevice));
     return SOCCER_OK;
 }
 
@@ -436,20 +439,107 @@ extern "C" int soccer_get_state(soccer_handle* h, int8_t* row_a, int8_t* col_a, 
     if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_get_state during graph capture");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const size_t n = h->P.n;
-    if (row_a) HIP_TRY(h, hipMemcpy(row_a, h->P.row_a, n, hipMemcpyDeviceToHost));
-    if (col_a) HIP_TRY(h, hipMemcpy(col_a, h->P.col_a, n, hipMemcpyDeviceToHost));
-    if (row_b) HIP_TRY(h, hipMemcpy(row_b, h->P.row_b, n, hipMemcpyDeviceToHost));
-    if (col_b) HIP_TRY(h, hipMemcpy(col_b, h->P.col_b, n, hipMemcpyDeviceToHost));
-    if (t) HIP_TRY(h, hipMemcpy(t, h->P.t, n, hipMemcpyDeviceToHost));
-    if (poss || needs_reset) {
-        std::vector<uint8_t> ps(n);
-        HIP_TRY(h, hipMemcpy(ps.data(), h->P.poss, n, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) {
-            if (poss) poss[i] = ps[i] & 1;
-            if (needs_reset) needs_reset[i] = (ps[i] >> 1) & 1;
-        }
+    const size_t n = h->P.n, S = h->state_stride;
+    std::vector<uint8_t> img(6 * S);
+    HIP_TRY(h, hipMemcpy(img.data(), h->d_state, 6 * S, hipMemcpyDeviceToHost));
+    if (row_a) std::memcpy(row_a, img.data(), n);
+    if (col_a) std::memcpy(col_a, img.data() + S, n);
+    if (row_b) std::memcpy(row_b, img.data() + 2 * S, n);
+    if (col_b) std::memcpy(col_b, img.data() + 3 * S, n);
+    if (t) std::memcpy(t, img.data() + 5 * S, n);
+    const uint8_t* ps = img.data() + 4 * S;
+    for (size_t i = 0; i < n; ++i) {
+        if (poss) poss[i] = ps[i] & 1;
+        if (needs_reset) needs_reset[i] = (ps[i] >> 1) & 1;
     }
+    return SOCCER_OK;
+}
+
+// ---- host-pointer entry points: stage through one pinned block, one copy each way ---------------
+namespace {
+struct StageLayout {
+    size_t act_a, act_b, u_step, u_reset, mask;            // inputs
+    size_t obs, final_obs, reward, term, trunc, code;      // outputs
+    size_t in_bytes, total;
+};
+StageLayout stage_layout(size_t n) {
+    auto up = [](size_t x) { return (x + 63) & ~size_t(63); };
+    StageLayout L{};
+    size_t o = 0;
+    L.u_step = o; o = up(o + 8 * n);
+    L.u_reset = o; o = up(o + 8 * n);
+    L.act_a = o; o = up(o + n);
+    L.act_b = o; o = up(o + n);
+    L.mask = o; o = up(o + n);
+    L.in_bytes = o;
+    L.obs = o; o = up(o + 2 * n);
+    L.final_obs = o; o = up(o + 2 * n);
+    L.reward = o; o = up(o + n);
+    L.term = o; o = up(o + n);
+    L.trunc = o; o = up(o + n);
+    L.code = o; o = up(o + n);
+    L.total = o;
+    return L;
+}
+int ensure_stage(soccer_handle* h, const StageLayout& L) {
+    if (h->stage_bytes >= L.total) return SOCCER_OK;
+    HIP_TRY(h, hipMalloc(&h->stage_dev, L.total));
+    HIP_TRY(h, hipHostMalloc(&h->stage_host, L.total, hipHostMallocDefault));
+    h->stage_bytes = L.total;
+    return SOCCER_OK;
+}
+}  // namespace
+
+extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_step_host during graph capture");
+    if (!a || !a->act_a || !a->act_b) return fail(h, SOCCER_E_INVALID, "batched_step: act_a and act_b are required");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t n = h->P.n;
+    const StageLayout L = stage_layout(n);
+    if (int rc = ensure_stage(h, L)) return rc;
+    uint8_t* H = h->stage_host; uint8_t* D = h->stage_dev;
+    std::memcpy(H + L.act_a, a->act_a, n); std::memcpy(H + L.act_b, a->act_b, n);
+    if (a->u_step) std::memcpy(H + L.u_step, a->u_step, 8 * n);
+    if (a->u_reset) std::memcpy(H + L.u_reset, a->u_reset, 8 * n);
+    HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
+    soccer_step_args d{};
+    d.act_a = reinterpret_cast<const int8_t*>(D + L.act_a); d.act_b = reinterpret_cast<const int8_t*>(D + L.act_b);
+    d.u_step = a->u_step ? reinterpret_cast<const double*>(D + L.u_step) : nullptr;
+    d.u_reset = a->u_reset ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr;
+    d.obs = reinterpret_cast<uint16_t*>(D + L.obs); d.final_obs = reinterpret_cast<uint16_t*>(D + L.final_obs);
+    d.reward = reinterpret_cast<int8_t*>(D + L.reward); d.terminated = D + L.term; d.truncated = D + L.trunc;
+    d.prob_code = D + L.code;
+    if (a->last_return) return fail(h, SOCCER_E_INVALID, "batched_step_host: last_return is device-only");
+    if (int rc = batched_step_ex(h, &d)) return rc;
+    HIP_TRY(h, hipMemcpyAsync(H + L.in_bytes, D + L.in_bytes, L.total - L.in_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (a->obs) std::memcpy(a->obs, H + L.obs, 2 * n);
+    if (a->final_obs) std::memcpy(a->final_obs, H + L.final_obs, 2 * n);
+    if (a->reward) std::memcpy(a->reward, H + L.reward, n);
+    if (a->terminated) std::memcpy(a->terminated, H + L.term, n);
+    if (a->truncated) std::memcpy(a->truncated, H + L.trunc, n);
+    if (a->prob_code) std::memcpy(a->prob_code, H + L.code, n);
+    return SOCCER_OK;
+}
+
+extern "C" int batched_reset_host(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_reset_host during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t n = h->P.n;
+    const StageLayout L = stage_layout(n);
+    if (int rc = ensure_stage(h, L)) return rc;
+    uint8_t* H = h->stage_host; uint8_t* D = h->stage_dev;
+    if (mask) std::memcpy(H + L.mask, mask, n);
+    if (u_reset) std::memcpy(H + L.u_reset, u_reset, 8 * n);
+    if (mask || u_reset) HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
+    if (int rc = batched_reset(h, mask ? D + L.mask : nullptr,
+                               u_reset ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr,
+                               reinterpret_cast<uint16_t*>(D + L.obs))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(H + L.obs, D + L.obs, 2 * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (obs) std::memcpy(obs, H + L.obs, 2 * n);
     return SOCCER_OK;
 }
 

@@ -1,0 +1,190 @@
+"""SoccerSimultaneousEnv — single-environment facade with the reference's Python surface.
+
+Drop-in for `gym_soccer.envs.SoccerSimultaneousEnv`
+(gym_soccer/envs/soccer_simultaneous_env.py:5-497): same constructor arguments (:35), same
+`reset(seed, options)` (:410-424) / `step(action_dict)` (:375-408) signatures, dict-of-agents I/O,
+scalar Python types, `AssertionError` on misuse, and the `env.state = tuple` injection hook the
+reference's tests rely on.  The transition itself is NOT computed here: every step is one launch of
+the HIP kernel on a 1-lane handle (libsoccer_hip.so, batched_step_host).
+
+Randomness: like the reference this env owns an `np.random.RandomState` (MT19937, :57-58) and
+draws exactly one uniform per reset and one per step (:395, :414); the uniform is handed to the
+kernel, so for a given seed the trajectories are the reference's own, step for step.
+"""
+import numpy as np
+
+from .. import spaces
+from ..core import SoccerBatch
+
+
+_ACTIONS = ['NOOP', 'NORTH', 'SOUTH', 'EAST', 'WEST']
+_MOVES = {0: (0, 0), 1: (0, -1), 2: (0, 1), 3: (1, 0), 4: (-1, 0)}    # (dcol, drow) (:24-30)
+
+
+class SoccerSimultaneousEnv:
+    NOOP, NORTH, SOUTH, EAST, WEST = 0, 1, 2, 3, 4
+    ACTION_STRING = _ACTIONS
+    ACTION_STRING_TO_INT = {k: v for v, k in enumerate(_ACTIONS)}
+    ACTION_INT_TO_MOVE = _MOVES
+    ACTION_STRING_TO_MOVE = {_ACTIONS[k]: v for k, v in _MOVES.items()}
+    MOVE_TO_ACTION_INT = {v: k for k, v in _MOVES.items()}
+    MOVE_TO_ACTION_STRING = {v: _ACTIONS[k] for k, v in _MOVES.items()}
+    TERMINAL_STATE = (-1, -1, -1, -1, -1)
+    metadata = {"render_modes": ["ansi"]}
+
+    def __init__(self, width=5, height=4, slip_prob=0.0, player_a_policy=None, player_b_policy=None,
+                 seed=0, device=0):
+        assert not (player_a_policy is not None and player_b_policy is not None), \
+            "Both players cannot have a policy. At least one must be None."
+        assert width >= 5, "Width must be at least 5 columns."
+        assert height >= 4, "Height must be at least 4 rows."
+        self._batch = SoccerBatch(1, width, height, slip_prob, seed=seed, autoreset=False, device=device)
+        self.width = width + 2                      # +2 goal columns (:48)
+        self.height = height
+        self.slip_prob = slip_prob
+        self.seed = seed
+        self.player_a_policy = player_a_policy
+        self.player_b_policy = player_b_policy
+        self.multiagent = player_a_policy is None and player_b_policy is None
+        self.return_agent = ['player_a', 'player_b'] if self.multiagent else \
+            ['player_a'] if player_a_policy is None else ['player_b']
+        self.np_random = np.random.RandomState()
+        self.np_random.seed(self.seed)
+        self.goal_rows = ((height - 1) // 2, height // 2) if height % 2 == 0 else \
+            (height // 2 - 1, height // 2, height // 2 + 1)
+        self.goal_cols = (0, self.width - 1)
+
+        # state_space / goal_states / unreachable_states from the library's rule tables
+        lut, goal_value, isd = self._batch.tables()
+        H, W = self.height, self.width
+        self.unreachable_states, self.goal_states = [], {}
+        self.state_space = {self.TERMINAL_STATE: 0}
+        idx = np.arange(lut.size)
+        p = idx & 1; r = idx >> 1
+        yb = r % W; r //= W; xb = r % H; r //= H; ya = r % W; xa = r // W
+        tuples = list(zip(xa.tolist(), ya.tolist(), xb.tolist(), yb.tolist(), p.tolist()))
+        for f, st in enumerate(tuples):
+            if lut[f] == 0xFFFF:
+                self.unreachable_states.append(st)
+            elif goal_value[f] != 0:
+                self.goal_states[st] = float(goal_value[f])
+            else:
+                self.state_space[st] = int(lut[f])
+        self.nS = self._batch.nS
+        assert self.nS == len(self.state_space), "State space should be the same length as the number of states"
+        self._reverse_state_space = {v: k for k, v in self.state_space.items()}
+        self.nA = len(self.ACTION_STRING)
+        self.observation_space = spaces.Dict({a: spaces.Discrete(self.nS) for a in self.return_agent})
+        self.action_space = spaces.Dict({a: spaces.Discrete(self.nA) for a in self.return_agent})
+        self.isd = [(1.0 / len(isd), tuple(int(x) for x in s)) for s in isd]
+        self.needs_reset = True
+        self.state = None                          # host mirror; authoritative (tests assign to it, :43)
+        self.observations = None
+        self.timestep = 0
+        self.lastaction = None
+
+    def _state_to_observation(self, state):
+        state = self.TERMINAL_STATE if state in self.goal_states else state
+        return self.state_space[state]
+
+    def _observation_to_state(self, observation):
+        return self._reverse_state_space[observation]
+
+    def _push_state(self):
+        """`env.state = tuple` (and env.timestep) set by the caller is what the next step starts from
+        (tests/test_deterministic_soccer_simultaneous_env.py:43): the host mirror is copied to the lane."""
+        st = tuple(int(x) for x in self.state)
+        if st == self.TERMINAL_STATE or (st not in self.state_space and st not in self.goal_states):
+            raise KeyError(st)                      # P_readable[self.state] in the reference (:394)
+        self._batch.set_state([st[0]], [st[1]], [st[2]], [st[3]], [st[4]],
+                              t=[min(max(int(self.timestep), 0), self._batch.max_steps)], needs_reset=[0])
+
+    def _pull_state(self):
+        s = self._batch.get_state()
+        self.state = (int(s["row_a"][0]), int(s["col_a"][0]), int(s["row_b"][0]), int(s["col_b"][0]), int(s["poss"][0]))
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self.np_random.seed(seed)
+        u = self.np_random.random()                  # one uniform per reset (:414)
+        obs = self._batch.reset_host(u_reset=[u])
+        self._pull_state()
+        p = 1.0 / len(self.isd)
+        self.observations = {a: int(obs[0]) for a in self.return_agent}
+        infos = {a: {"p": np.round(p, 2)} for a in self.return_agent}
+        self.lastaction = None
+        self.needs_reset = False
+        self.timestep = 0
+        return self.observations, infos
+
+    def step(self, action):
+        assert not self.needs_reset, "Please reset the environment before taking a step"
+        assert isinstance(action, dict), "Action must be a dictionary"
+        assert len(action) == 1 or len(action) == 2, "Action must be a dictionary of length 1 or 2"
+        assert self.player_a_policy is not None or 'player_a' in action, "A policy for player_a must be provided"
+        assert self.player_b_policy is not None or 'player_b' in action, "A policy for player_b must be provided"
+        if self.multiagent:
+            assert len(action) == 2, "Action must be a dictionary of length 2 for multiagent case"
+            assert 'player_a' in action and 'player_b' in action, "Action must contain both 'player_a' and 'player_b'"
+        else:
+            assert len(action) == 1, "Action must be a dictionary of length 1 for single agent case"
+            assert 'player_a' in action or 'player_b' in action, "Action must contain either 'player_a' or 'player_b'"
+        self._push_state()
+        # the fixed side's action is looked up by the current observation (:187-188)
+        s = self._state_to_observation(tuple(self.state))
+        aa = int(action['player_a']) if self.player_a_policy is None else int(self.player_a_policy[s])
+        ab = int(action['player_b']) if self.player_b_policy is None else int(self.player_b_policy[s])
+        assert 0 <= aa < self.nA and 0 <= ab < self.nA, "actions must be in 0..4"
+        u = self.np_random.random()                  # one uniform per step (:395)
+        out = self._batch.step_host([aa], [ab], u_step=[u])
+        self._pull_state()
+        prob = self._batch.prob_table[int(out["prob_code"][0])]
+        reward = float(out["reward"][0])
+        done = bool(out["terminated"][0])
+        self.observations = {a: int(out["obs"][0]) for a in self.return_agent}
+        self.lastaction = action
+        self.timestep += 1
+        if self.multiagent:
+            rewards = {'player_a': reward, 'player_b': reward * -1}
+        else:                                        # learner-B tables store the flipped sign (:243-244)
+            rewards = {a: (reward if a == 'player_a' else -1 * reward) for a in self.return_agent}
+        dones = {a: done for a in self.return_agent}
+        truncateds = {a: self.timestep >= 100 for a in self.return_agent}
+        infos = {a: {"p": np.round(prob, 2)} for a in self.return_agent}
+        self.needs_reset = any(dones.values()) or any(truncateds.values())
+        return self.observations, rewards, dones, truncateds, infos
+
+    def render(self):
+        """ASCII pitch (host-side debug print; the reference's :426-485)."""
+        xa, ya, xb, yb, p = self.state
+        W, H = self.width, self.height
+        print(self.state)
+        print(f"Player A position: x={xa}, y={ya}, possession={p == 0}")
+        print(f"Player B position: x={xb}, y={yb}, possession={p == 1}")
+        lines = ['  ' + '-' * (W * 2 - 4)]
+        for r in range(H):
+            cells = []
+            for c in range(W):
+                mark = '  '
+                if (r, c) == (xa, ya): mark = 'A' + ('*' if p == 0 else ' ')
+                if (r, c) == (xb, yb): mark = 'B' + ('*' if p == 1 else ' ')
+                cells.append(mark)
+            if r in self.goal_rows:
+                left = cells[0] if '*' in cells[0] else '||'
+                right = cells[-1] if '*' in cells[-1] else '||'
+            else:
+                left, right = ' |', '| '
+            lines.append(left + ''.join(cells[1:-1]) + right)
+        lines.append('  ' + '-' * (W * 2 - 4))
+        for ln in lines:
+            print(ln)
+        print(f"Ball possession: {'A' if p == 0 else 'B'}")
+        carrier_col, carrier_row = (ya, xa) if p == 0 else (yb, xb)
+        if carrier_row in self.goal_rows and carrier_col in self.goal_cols:
+            scorer_is_a = carrier_col == W - 1
+            own = (p == 0) != scorer_is_a
+            who = 'A' if p == 0 else 'B'
+            print(f"OWN GOAL! Player {who} scored in their own goal!" if own else f"GOAL! Player {who} scored!")
+
+    def close(self):
+        self._batch.close()

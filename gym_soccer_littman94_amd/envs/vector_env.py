@@ -1,0 +1,153 @@
+"""VectorSoccerEnv — N independent SoccerSimultaneous environments resident on one MI355X.
+
+The reference has no vector env; this is the batched form of `SoccerSimultaneousEnv.step/reset`
+(gym_soccer/envs/soccer_simultaneous_env.py:375-424) with the gym-0.26 `VectorEnv` conventions the
+reference leaves undefined:
+  * dict-of-agents I/O like the reference, every value an array of length `num_envs`;
+  * auto-reset (default): a lane that terminates or truncates is reset inside the same step; the
+    returned observation is the first one of the new episode and `infos["final_observation"]`
+    carries the terminal one (`infos["_final_observation"]` marks the lanes it applies to);
+  * rewards float32 (+r for player_a, -r for player_b, :400-402), terminated/truncated bool.
+
+Two I/O modes:
+  * numpy (default): actions are host arrays; results come back as numpy arrays (one staged copy
+    in, one kernel, one staged copy out per step);
+  * device: actions are torch CUDA int8 tensors; results are torch tensors living in buffers the env
+    owns, nothing is synchronised — the mode for rollout loops that stay on the GPU.
+Per-lane randomness is Philox4x32-10 keyed by (seed, global lane id, tick): include/soccer_hip.h.
+"""
+import numpy as np
+
+from .. import spaces
+from ..core import SoccerBatch
+
+AGENTS = ('player_a', 'player_b')
+
+
+class VectorSoccerEnv:
+    metadata = {"render_modes": []}
+
+    def __init__(self, num_envs, width=5, height=4, slip_prob=0.0, seed=0, autoreset=True,
+                 device=0, lane_offset=0, max_episode_steps=100, io="numpy", strict=True,
+                 envs_per_thread=0):
+        assert io in ("numpy", "device"), "io must be 'numpy' or 'device'"
+        self.num_envs = int(num_envs)
+        self.io = io
+        self.strict = strict
+        stream = None
+        if io == "device":
+            import torch
+            self._torch = torch
+            self._dev = torch.device("cuda", device)
+            stream = torch.cuda.current_stream(self._dev).cuda_stream   # results are ordered with torch work
+        self._batch = SoccerBatch(self.num_envs, width, height, slip_prob, seed=seed, autoreset=autoreset,
+                                  max_steps=max_episode_steps, device=device, lane_offset=lane_offset,
+                                  stream=stream, envs_per_thread=envs_per_thread)
+        b = self._batch
+        self.width, self.height, self.slip_prob = width + 2, height, slip_prob
+        self.nS, self.nA = b.nS, b.nA
+        self.autoreset = bool(autoreset)
+        self.return_agent = list(AGENTS)
+        self.multiagent = True
+        self.single_observation_space = spaces.Dict({a: spaces.Discrete(self.nS) for a in AGENTS})
+        self.single_action_space = spaces.Dict({a: spaces.Discrete(self.nA) for a in AGENTS})
+        self.observation_space = spaces.Dict(
+            {a: spaces.MultiDiscrete(np.full(self.num_envs, self.nS)) for a in AGENTS})
+        self.action_space = spaces.Dict(
+            {a: spaces.MultiDiscrete(np.full(self.num_envs, self.nA)) for a in AGENTS})
+        self._needs_reset = True
+        if io == "device":
+            t, n, d = self._torch, self.num_envs, self._dev
+            u16 = getattr(t, "uint16", t.int16)
+            self._obs = t.zeros(n, dtype=u16, device=d); self._fin = t.zeros(n, dtype=u16, device=d)
+            self._rew = t.zeros(n, dtype=t.int8, device=d)
+            self._term = t.zeros(n, dtype=t.uint8, device=d); self._trunc = t.zeros(n, dtype=t.uint8, device=d)
+            self._code = t.zeros(n, dtype=t.uint8, device=d)
+            self._prob = t.tensor(np.round(b.prob_table, 2), dtype=t.float64, device=d)
+
+    # ---------------------------------------------------------------------------------------------
+    def reset(self, seed=None, options=None, mask=None):
+        """Reset every lane (or the lanes selected by `mask`, e.g. the finished ones when auto-reset
+        is off).  `seed` re-keys the per-lane Philox streams (np_random.seed in the reference, :411-412)."""
+        b = self._batch
+        if seed is not None:
+            b.seed(seed)
+        p = np.round(1.0 / b.n_isd, 2)
+        if self.io == "numpy":
+            obs = b.reset_host(mask=mask)
+            infos = {a: {"p": np.full(self.num_envs, p)} for a in AGENTS}
+            self._needs_reset = False
+            return {a: obs for a in AGENTS}, infos
+        m = None if mask is None else mask.to(self._torch.uint8)
+        b.reset(mask=m, obs=self._obs)
+        self._needs_reset = False
+        infos = {a: {"p": self._torch.full((self.num_envs,), float(p), device=self._dev)} for a in AGENTS}
+        return {a: self._obs for a in AGENTS}, infos
+
+    def _check_actions(self, action):
+        assert isinstance(action, dict), "Action must be a dictionary"
+        assert len(action) == 2, "Action must be a dictionary of length 2 for multiagent case"
+        assert 'player_a' in action and 'player_b' in action, "Action must contain both 'player_a' and 'player_b'"
+        return action['player_a'], action['player_b']
+
+    def step(self, action):
+        assert not self._needs_reset, "Please reset the environment before taking a step"
+        a, bb = self._check_actions(action)
+        b = self._batch
+        n = self.num_envs
+        if self.io == "numpy":
+            a = np.asarray(a); bb = np.asarray(bb)
+            assert a.shape == (n,) and bb.shape == (n,), "one action per environment and agent"
+            assert ((a >= 0) & (a < self.nA)).all() and ((bb >= 0) & (bb < self.nA)).all(), "actions must be in 0..4"
+            out = b.step_host(a.astype(np.int8, copy=False), bb.astype(np.int8, copy=False))
+            if self.strict:
+                self._raise_on_misuse()
+            r = out["reward"].astype(np.float32)
+            term = out["terminated"].view(np.bool_); trunc = out["truncated"].view(np.bool_)
+            p = np.round(b.prob_table[out["prob_code"]], 2)
+            fin_mask = term | trunc
+            infos = {ag: {"p": p} for ag in AGENTS}
+            infos["final_observation"] = {ag: out["final_obs"] for ag in AGENTS}
+            infos["_final_observation"] = fin_mask
+            return ({ag: out["obs"] for ag in AGENTS}, {'player_a': r, 'player_b': -r},
+                    {ag: term for ag in AGENTS}, {ag: trunc for ag in AGENTS}, infos)
+        t = self._torch
+        assert a.dtype == t.int8 and bb.dtype == t.int8 and a.is_cuda and bb.is_cuda, \
+            "device io expects torch.int8 CUDA tensors (values 0..4; not re-validated on the hot path)"
+        assert a.shape == (n,) and bb.shape == (n,) and a.is_contiguous() and bb.is_contiguous()
+        b.step(a, bb, obs=self._obs, reward=self._rew, terminated=self._term, truncated=self._trunc,
+               prob_code=self._code, final_obs=self._fin)
+        r = self._rew.to(t.float32)
+        term = self._term.bool(); trunc = self._trunc.bool()
+        infos = {ag: {"p": self._prob[self._code.long()]} for ag in AGENTS}
+        infos["final_observation"] = {ag: self._fin for ag in AGENTS}
+        infos["_final_observation"] = term | trunc
+        return ({ag: self._obs for ag in AGENTS}, {'player_a': r, 'player_b': -r},
+                {ag: term for ag in AGENTS}, {ag: trunc for ag in AGENTS}, infos)
+
+    def _raise_on_misuse(self):
+        hist, misuse = self._batch.stats()
+        if misuse:
+            self._batch.reset_stats()
+            raise AssertionError("Please reset the environment before taking a step "
+                                 "(some lanes had terminated or truncated; they were left untouched)")
+
+    # ---------------------------------------------------------------------------------------------
+    def get_state(self):
+        """dict of int8/uint8 arrays: row_a, col_a, row_b, col_b, poss, t, needs_reset."""
+        return self._batch.get_state()
+
+    def set_state(self, **kw):
+        self._batch.set_state(**kw)
+        self._needs_reset = False
+
+    def episode_histogram(self):
+        """Counts of finished episodes by player A's return (-1, 0, +1)."""
+        return self._batch.stats()[0]
+
+    @property
+    def batch(self):
+        return self._batch
+
+    def close(self):
+        self._batch.close()

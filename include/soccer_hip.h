@@ -63,6 +63,7 @@ extern "C" {
 
 /* cfg.flags */
 #define SOCCER_F_AUTORESET   1u  /* lanes that terminate/truncate are reset inside the same step */
+#define SOCCER_F_NULL_STREAM 2u  /* enqueue on the device's default (null) stream; cfg.stream ignored */
 
 /* actions (soccer_simultaneous_env.py:8-12); moves are (dcol,drow) (:24-30) */
 #define SOCCER_NOOP  0
@@ -149,6 +150,13 @@ int batched_step(soccer_handle* h, const int8_t* act_a, const int8_t* act_b,
                  uint8_t* prob_code);
 int batched_step_ex(soccer_handle* h, const soccer_step_args* args);
 int batched_rollout(soccer_handle* h, const soccer_rollout_args* args);
+
+/* Host-pointer variants for small batches and numpy callers (the single-env facade): identical
+ * semantics, but every array pointer is HOST memory.  The call stages inputs through one pinned
+ * block (one copy in, one kernel, one copy out) and returns when the results are in the caller's
+ * arrays.  last_return must be NULL. */
+int batched_step_host(soccer_handle* h, const soccer_step_args* host_args);
+int batched_reset_host(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs);
 
 /* ---- state injection / readback (`env.state = tuple`, tests/test_deterministic...py:43) -- */
 /* HOST pointers of n_lanes elements; any pointer may be NULL (field left unchanged / not read).

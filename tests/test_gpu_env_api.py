@@ -1,0 +1,342 @@
+"""-m gpu: the gym-style host layer (SoccerSimultaneousEnv facade, VectorSoccerEnv, make) on top of
+the HIP path.  The known-answer vectors are the reference's own
+(gym_soccer/tests/test_deterministic_soccer_simultaneous_env.py, restated as data — SURVEY.md
+Appendix B); the API-shape checks follow gym_soccer/tests/test_general.py:159-302."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import gym_soccer_littman94_amd as gsa
+from gym_soccer_littman94_amd import SoccerSimultaneousEnv, VectorSoccerEnv
+from oracle.oracle import Oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRAJS = sorted(glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
+N, S, E, W, O = 1, 2, 3, 4, 0     # NORTH, SOUTH, EAST, WEST, NOOP
+
+
+@pytest.fixture(scope="module")
+def env():
+    e = SoccerSimultaneousEnv(width=5, height=4, slip_prob=0.0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def slip_env():
+    e = SoccerSimultaneousEnv(width=5, height=4, slip_prob=0.2)
+    yield e
+    e.close()
+
+
+def step_from(env, state, a, b):
+    env.reset()
+    env.state = state
+    return env.step({'player_a': a, 'player_b': b})
+
+
+# ---- drop-in proof: same seed, same actions => the reference's own MT19937 trajectories ----------
+@pytest.mark.parametrize("path", TRAJS, ids=[os.path.basename(p)[:-4] for p in TRAJS])
+def test_same_seed_reproduces_reference_trajectories(path):
+    g = np.load(path)
+    env = SoccerSimultaneousEnv(width=5, height=4, slip_prob=float(g["slip"]))
+    obs, info = env.reset(seed=int(g["seed"]))
+    assert obs['player_a'] == g["first_obs"] == obs['player_b'] and info['player_a']['p'] == 0.25
+    n = 600
+    for k in range(n):
+        if env.needs_reset:
+            assert g["reset_before"][k]
+            obs, _ = env.reset()
+            assert obs['player_a'] == g["reset_obs"][k]
+        else:
+            assert not g["reset_before"][k]
+        o, r, d, t, i = env.step({'player_a': int(g["actions"][k, 0]), 'player_b': int(g["actions"][k, 1])})
+        assert o['player_a'] == o['player_b'] == g["obs"][k], k
+        assert r['player_a'] == g["reward_a"][k] and r['player_b'] == g["reward_b"][k]
+        assert d['player_a'] == bool(g["terminated"][k]) and t['player_b'] == bool(g["truncated"][k])
+        assert i['player_a']['p'] == g["p"][k] == i['player_b']['p']
+        assert env.state == tuple(g["state"][k])
+    env.close()
+
+
+# ---- known-answer vectors of the reference's deterministic tests ---------------------------------
+def test_initialization_and_shapes(env):
+    assert env.width == 7 and env.height == 4 and env.slip_prob == 0.0
+    assert env.action_space['player_a'].n == 5 and env.action_space['player_b'].n == 5
+    assert env.observation_space['player_a'].n == 761 == env.nS
+    assert len(env.state_space) == 761 and len(env.goal_states) == 160 and len(env.unreachable_states) == 648
+    assert env.state_space[(0, 1, 0, 2, 0)] == 1 and env.state_space[(3, 5, 3, 4, 1)] == 760
+    assert env.isd == [(0.25, (1, 2, 2, 4, 0)), (0.25, (1, 2, 2, 4, 1)), (0.25, (2, 2, 1, 4, 0)), (0.25, (2, 2, 1, 4, 1))]
+    obs, info = env.reset()
+    assert isinstance(obs, dict) and isinstance(info, dict) and set(obs) == set(info) == {'player_a', 'player_b'}
+    assert obs['player_a'] in (253, 254, 435, 436)
+    out = env.step({'player_a': O, 'player_b': O})
+    assert len(out) == 5 and all(isinstance(x, dict) for x in out)
+
+
+@pytest.mark.parametrize("state,a,b,ra", [
+    ((1, 5, 3, 1, 0), E, O, +1), ((3, 5, 1, 1, 1), O, W, -1),                  # scoring (:49,:52)
+    ((1, 1, 3, 5, 0), W, O, -1), ((2, 1, 3, 5, 0), W, O, -1),                  # own goals (:56-84)
+    ((3, 1, 1, 5, 1), O, E, +1), ((3, 1, 2, 5, 1), O, E, +1),
+    ((1, 5, 1, 1, 0), E, W, +1), ((1, 5, 1, 1, 1), E, W, -1),                  # simultaneous attempts (:343-352)
+    ((1, 5, 3, 3, 0), E, O, +1), ((2, 1, 3, 3, 0), W, O, -1),                  # goal-edge scoring (:411-421)
+])
+def test_goals(env, state, a, b, ra):
+    o, r, d, t, i = step_from(env, state, a, b)
+    assert d['player_a'] and d['player_b']
+    assert r['player_a'] == ra and r['player_b'] == -ra
+    assert o['player_a'] == 0 and env.needs_reset
+    assert isinstance(r['player_a'], float) and isinstance(d['player_a'], bool) and isinstance(t['player_a'], bool)
+
+
+@pytest.mark.parametrize("state,a,b", [
+    ((1, 2, 1, 3, 0), E, W), ((1, 2, 1, 3, 1), E, W),          # head-on swap (:89-100)
+    ((1, 2, 1, 3, 0), E, O), ((1, 2, 1, 3, 1), O, W),          # into a stander (:105-116)
+])
+def test_collisions_leave_positions(env, state, a, b):
+    step_from(env, state, a, b)
+    assert env.state[:4] == state[:4] and env.state[4] in (0, 1)
+
+
+def test_stander_collision_flips_possession(env):
+    step_from(env, (1, 2, 1, 3, 0), E, O); assert env.state == (1, 2, 1, 3, 1)
+    step_from(env, (1, 2, 1, 3, 1), O, W); assert env.state == (1, 2, 1, 3, 0)
+
+
+@pytest.mark.parametrize("p", [0, 1])
+@pytest.mark.parametrize("a,b,sa,sb", [(N, E, (0, 1), (3, 5)), (W, E, (0, 1), (3, 5)), (N, S, (0, 1), (3, 5)),
+                                       (W, S, (0, 1), (3, 5)), (E, N, (3, 5), (0, 1)), (E, W, (3, 5), (0, 1)),
+                                       (S, N, (3, 5), (0, 1)), (S, W, (3, 5), (0, 1))])
+def test_walls_and_corners_bounce(env, p, a, b, sa, sb):      # :170-264
+    state = sa + sb + (p,)
+    step_from(env, state, a, b)
+    assert env.state == state
+
+
+@pytest.mark.parametrize("state,a,b", [
+    ((1, 1, 3, 3, 1), W, O), ((2, 1, 3, 3, 1), W, O), ((3, 3, 1, 5, 0), O, E), ((3, 3, 2, 5, 0), O, E),
+    ((3, 3, 1, 1, 0), O, W), ((3, 3, 2, 1, 0), O, W), ((1, 5, 3, 3, 1), E, O), ((2, 5, 3, 3, 1), E, O)])
+def test_cannot_enter_goal_without_ball(env, state, a, b):    # :268-321
+    o, r, d, t, i = step_from(env, state, a, b)
+    assert env.state == state and not d['player_a'] and r['player_a'] == 0
+
+
+def test_follow_and_out_of_bounds(env):
+    for p in (0, 1):                                          # no possession change without collision (:333-339)
+        step_from(env, (1, 1, 3, 3, p), E, W); assert env.state[4] == p
+        step_from(env, (1, 1, 1, 2, p), E, E); assert env.state == (1, 2, 1, 3, p)   # follow the leader (:356-371)
+        step_from(env, (1, 1, 1, 3, p), E, E); assert env.state == (1, 2, 1, 4, p)
+    step_from(env, (0, 1, 3, 5, 0), N, E); assert env.state == (0, 1, 3, 5, 0)       # :398-407
+    step_from(env, (0, 1, 3, 4, 1), N, E); assert env.state == (0, 1, 3, 5, 1)
+
+
+@pytest.mark.parametrize("state,a,b", [((1, 1, 2, 2, 0), E, N), ((1, 2, 2, 1, 1), W, N), ((2, 1, 1, 2, 0), E, S),
+                                       ((1, 1, 1, 3, 1), E, W), ((1, 3, 1, 1, 0), W, E), ((1, 1, 3, 1, 0), S, N),
+                                       ((3, 1, 1, 1, 1), N, S)])
+def test_same_target_cell_four_way_tie(env, state, a, b):     # :146-165, frequencies 0.45..0.55 over 1000 trials
+    moved_a = moved_b = switched = 0
+    for _ in range(1000):
+        step_from(env, state, a, b)
+        moved_a += env.state[:2] != state[:2]; moved_b += env.state[2:4] != state[2:4]
+        switched += env.state[4] != state[4]
+    assert moved_a + moved_b == 1000
+    for c in (moved_a, moved_b, switched):
+        assert 450 <= c <= 550
+
+
+def test_captured_vectors_with_injected_uniforms(env):
+    """SURVEY.md Appendix B 'additional vectors' (measured on the reference with an injected u)."""
+    class U:
+        def __init__(self, u): self.u = u
+        def random(self): return self.u
+        def seed(self, s): pass
+    rs = env.np_random
+    try:
+        for u, exp, ob in [(0.49999, (1, 2, 1, 3, 0), 241), (0.5, (1, 2, 1, 3, 1), 242)]:
+            env.np_random = rs; env.reset(); env.state = (1, 2, 1, 3, 0); env.np_random = U(u)
+            o, r, d, t, i = env.step({'player_a': E, 'player_b': W})
+            assert env.state == exp and o['player_a'] == ob and i['player_a']['p'] == 0.5
+        for u, exp, ob in [(0.0, (1, 1, 1, 2, 0), 201), (0.25, (1, 1, 1, 2, 1), 202),
+                           (0.5, (1, 2, 2, 2, 0), 249), (0.75, (1, 2, 2, 2, 1), 250)]:
+            env.np_random = rs; env.reset(); env.state = (1, 1, 2, 2, 0); env.np_random = U(u)
+            o, r, d, t, i = env.step({'player_a': E, 'player_b': N})
+            assert env.state == exp and o['player_a'] == ob and i['player_a']['p'] == 0.25
+        env.np_random = rs; env.reset(); env.state = (1, 2, 2, 4, 0); env.timestep = 99
+        o, r, d, t, i = env.step({'player_a': O, 'player_b': O})
+        assert t['player_a'] and not d['player_a'] and env.needs_reset
+        env.reset(); env.state = (1, 6, 3, 3, 0)                 # stepping from a goal tuple: absorbing
+        o, r, d, t, i = env.step({'player_a': E, 'player_b': O})
+        assert o['player_a'] == 0 and r['player_a'] == 0 and d['player_a'] and env.state == (1, 6, 3, 3, 0)
+        for u, ob in [(0.0, 253), (0.2499, 253), (0.25, 254), (0.5, 435), (0.75, 436), (0.99999, 436)]:
+            env.np_random = U(u)
+            assert env.reset()[0]['player_a'] == ob
+    finally:
+        env.np_random = rs
+
+
+def test_assertions_like_the_reference(env):
+    fresh = SoccerSimultaneousEnv()
+    with pytest.raises(AssertionError, match="reset"):
+        fresh.step({'player_a': 0, 'player_b': 0})             # :376
+    fresh.close()
+    env.reset()
+    for bad in ([0, 0], {'player_a': 0}, {'player_a': 0, 'x': 1}, {'player_a': 0, 'player_b': 0, 'c': 0}):
+        with pytest.raises(AssertionError):
+            env.step(bad)
+    step_from(env, (1, 5, 3, 1, 0), E, O)
+    with pytest.raises(AssertionError, match="reset"):          # done -> needs reset (:406)
+        env.step({'player_a': 0, 'player_b': 0})
+    env.reset(); env.state = (1, 1, 1, 1, 0)
+    with pytest.raises(KeyError):                                # no table entry for unreachable tuples (:394)
+        env.step({'player_a': 0, 'player_b': 0})
+    for kw in (dict(width=4), dict(height=3), dict(player_a_policy={0: 0}, player_b_policy={0: 0})):
+        with pytest.raises(AssertionError):
+            SoccerSimultaneousEnv(**kw)
+
+
+@pytest.mark.parametrize("learner", ["player_a", "player_b"])
+def test_single_agent_mode_matches_reference_tables(learner):
+    """Fixed-opponent mode (reference :54-56, :187-188, :243-244): the sampled transition must be an
+    entry of the reference's single-agent table for (state, learner action), with the reward sign of
+    that table, and over many draws every entry must show up."""
+    g = np.load(os.path.join(GOLDEN, "single_5x4_s0p2_%s.npz" % learner))
+    policy = {s: int(a) for s, a in enumerate(g["policy"])}
+    kw = {"player_b_policy": policy} if learner == "player_a" else {"player_a_policy": policy}
+    env = SoccerSimultaneousEnv(width=5, height=4, slip_prob=0.2, **kw)
+    assert not env.multiagent and env.return_agent == [learner]
+    assert list(env.observation_space) == [learner] and env.action_space[learner].n == 5
+    rows = g["rows"]       # xa,ya,xb,yb,p, a, k, nxa,nya,nxb,nyb,np, reward, done
+    table = {}
+    for row in rows:
+        table.setdefault((tuple(row[:5]), int(row[5])), set()).add((tuple(row[7:12]), int(row[12]), int(row[13])))
+    rng = np.random.RandomState(0)
+    keys = [k for k in table if k[0] not in env.goal_states]
+    for idx in rng.choice(len(keys), 300, replace=False):
+        st, a = keys[idx]
+        env.reset(); env.state = st
+        o, r, d, t, i = env.step({learner: a})
+        assert set(o) == set(r) == set(d) == set(t) == set(i) == {learner}
+        assert (env.state, int(r[learner]), int(d[learner])) in table[(st, a)]
+    env.close()
+
+
+def test_slip_probabilities_show_up_in_info_p(slip_env):
+    seen = set()
+    for _ in range(400):
+        slip_env.reset(); slip_env.state = (1, 2, 2, 4, 0)
+        o, r, d, t, i = slip_env.step({'player_a': E, 'player_b': W})
+        seen.add(float(i['player_a']['p']))
+    assert seen <= {0.64, 0.08, 0.01} and 0.64 in seen and 0.08 in seen
+    # NOOP never slips (tests/test_slip_soccer_simultaneous_env.py:198-210)
+    for _ in range(50):
+        slip_env.reset(); slip_env.state = (1, 2, 3, 4, 0)
+        slip_env.step({'player_a': O, 'player_b': O})
+        assert slip_env.state == (1, 2, 3, 4, 0)
+
+
+def test_render_smoke(env, capsys):
+    env.reset(); env.state = (1, 5, 3, 1, 0)
+    env.step({'player_a': E, 'player_b': O})
+    env.render()
+    out = capsys.readouterr().out
+    assert "GOAL! Player A scored!" in out and "Ball possession: A" in out
+
+
+# ---- VectorSoccerEnv ------------------------------------------------------------------------------
+def test_vector_env_numpy_matches_oracle_and_gym_autoreset_convention():
+    n, T = 2048, 150
+    rng = np.random.default_rng(1)
+    v = VectorSoccerEnv(n, slip_prob=0.2, seed=11)
+    o = Oracle(5, 4, 0.2, n=n, seed=11, autoreset=True)
+    assert v.num_envs == n and v.single_observation_space['player_a'].n == 761
+    assert v.action_space['player_b'].nvec.shape == (n,)
+    with pytest.raises(AssertionError, match="reset"):
+        v.step({'player_a': np.zeros(n, int), 'player_b': np.zeros(n, int)})
+    obs, info = v.reset(seed=11)
+    np.testing.assert_array_equal(obs['player_a'], o.reset())
+    assert info['player_b']['p'].shape == (n,) and (info['player_a']['p'] == 0.25).all()
+    saw_final = 0
+    for k in range(T):
+        a = rng.integers(0, 5, size=(2, n))
+        ob, rw, te, tr, inf = v.step({'player_a': a[0], 'player_b': a[1]})
+        c = o.step(a[0], a[1])
+        np.testing.assert_array_equal(ob['player_a'], c["obs"]); assert ob['player_b'] is ob['player_a']
+        np.testing.assert_array_equal(rw['player_a'], c["reward"].astype(np.float32))
+        np.testing.assert_array_equal(rw['player_b'], -c["reward"].astype(np.float32))
+        assert rw['player_a'].dtype == np.float32 and te['player_a'].dtype == np.bool_ and tr['player_a'].dtype == np.bool_
+        np.testing.assert_array_equal(te['player_a'], c["terminated"].astype(bool))
+        np.testing.assert_array_equal(tr['player_b'], c["truncated"].astype(bool))
+        np.testing.assert_array_equal(inf['player_a']['p'], np.round(c["prob"], 2))
+        fin = inf["_final_observation"]
+        np.testing.assert_array_equal(fin, (c["terminated"] | c["truncated"]).astype(bool))
+        np.testing.assert_array_equal(inf["final_observation"]['player_a'], c["final_obs"])
+        # finished lanes already show the first observation of their next episode
+        assert np.isin(ob['player_a'][fin], (253, 254, 435, 436)).all()
+        assert (inf["final_observation"]['player_a'][te['player_a']] == 0).all()
+        saw_final += int(fin.sum())
+    assert saw_final > n and int(v.episode_histogram().sum()) == saw_final
+    for bad in ({'player_a': a[0]}, [a[0], a[1]], {'player_a': a[0] + 5, 'player_b': a[1]},
+                {'player_a': a[0][:-1], 'player_b': a[1]}):
+        with pytest.raises(AssertionError):
+            v.step(bad)
+    v.close()
+
+
+def test_vector_env_without_autoreset_is_strict_like_the_reference():
+    n = 512
+    rng = np.random.default_rng(2)
+    v = VectorSoccerEnv(n, slip_prob=0.0, seed=3, autoreset=False)
+    v.reset()
+    done = np.zeros(n, bool)
+    with pytest.raises(AssertionError, match="reset"):
+        for k in range(120):
+            a = rng.integers(0, 5, size=(2, n))
+            ob, rw, te, tr, inf = v.step({'player_a': a[0], 'player_b': a[1]})
+            done |= te['player_a'] | tr['player_a']
+    assert done.any()
+    s = v.get_state()
+    need = s["needs_reset"].astype(bool)
+    assert (need | ~done).all()          # every lane we saw finish is parked (the last step may add more)
+    ob, _ = v.reset(mask=need)
+    assert not v.get_state()["needs_reset"].any()
+    v.close()
+
+
+def test_vector_env_device_io_matches_numpy_io():
+    import torch
+    n, T = 4096, 60
+    rng = np.random.default_rng(4)
+    vn = VectorSoccerEnv(n, slip_prob=0.2, seed=21)
+    vd = VectorSoccerEnv(n, slip_prob=0.2, seed=21, io="device")
+    on, _ = vn.reset(); od, _ = vd.reset()
+    np.testing.assert_array_equal(on['player_a'], od['player_a'].cpu().numpy().astype(np.uint16))
+    for k in range(T):
+        a = rng.integers(0, 5, size=(2, n)).astype(np.int8)
+        rn = vn.step({'player_a': a[0], 'player_b': a[1]})
+        ta = torch.from_numpy(a[0]).cuda(); tb = torch.from_numpy(a[1]).cuda()
+        rd = vd.step({'player_a': ta, 'player_b': tb})
+        np.testing.assert_array_equal(rn[0]['player_a'], rd[0]['player_a'].cpu().numpy().astype(np.uint16))
+        np.testing.assert_array_equal(rn[1]['player_b'], rd[1]['player_b'].cpu().numpy())
+        np.testing.assert_array_equal(rn[2]['player_a'], rd[2]['player_a'].cpu().numpy())
+        np.testing.assert_array_equal(rn[3]['player_a'], rd[3]['player_a'].cpu().numpy())
+        np.testing.assert_array_equal(rn[4]['player_a']['p'], rd[4]['player_a']['p'].cpu().numpy())
+        np.testing.assert_array_equal(rn[4]["_final_observation"], rd[4]["_final_observation"].cpu().numpy())
+    vn.close(); vd.close()
+
+
+def test_make_ids():
+    e = gsa.make("SoccerLittman94-v0")
+    assert isinstance(e, SoccerSimultaneousEnv) and e.slip_prob == 0.0
+    e.close()
+    e = gsa.make("SoccerSimultaneous-v0")
+    assert e.slip_prob == 0.2 and e.width == 7
+    e.close()
+    v = gsa.make("VectorSoccerLittman94-v0", num_envs=64)
+    assert isinstance(v, VectorSoccerEnv) and v.num_envs == 64
+    v.close()
+    with pytest.raises(KeyError):
+        gsa.make("WalkFive-v0")
