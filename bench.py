@@ -90,10 +90,13 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gym_soccer_littman94_amd import SoccerBatch
+    from gym_soccer_littman94_amd.distributed import gather_lane_values, reduce_histogram, shard_range
     N, K, W = args.lanes, args.steps, args.warmup
+    lane_lo, lane_hi = shard_range(world * N, rank, world)      # contiguous global lane ids of this rank
+    assert lane_hi - lane_lo == N
     K += K % 2                                   # a captured sequence holds an even number of launches
     b = SoccerBatch(N, 5, 4, args.slip, seed=0, autoreset=True, device=local_rank,
-                    lane_offset=rank * N, envs_per_thread=args.envs_per_thread)
+                    lane_offset=lane_lo, envs_per_thread=args.envs_per_thread)
 
     # synthetic inputs, resident in HBM before the timed region: uniform-random joint actions for
     # every step; outputs stream into [K, N] trajectory buffers (nothing is cached or skipped)
@@ -149,12 +152,8 @@ def main():
     assert misuse == 0
     gathered = None
     if world > 1:
-        parts = [torch.empty_like(last_ret) for _ in range(world)]
-        dist.all_gather(parts, last_ret)            # RCCL over xGMI, int8[N] per rank
-        gathered = torch.cat(parts)
-        h = torch.tensor(hist.astype(np.int64), device=dev)
-        dist.all_reduce(h)
-        hist = h.cpu().numpy()
+        gathered = gather_lane_values(last_ret, world * N)      # RCCL all_gather over xGMI, int8[N] per rank
+        hist = np.array(reduce_histogram(hist, device=dev))
     else:
         gathered = last_ret
     # cheap end-to-end sanity on the real outputs of the timed steps (not a parity test)

@@ -1,0 +1,71 @@
+"""world_size-2 gloo test of the N>1 path on CPU: lane sharding by global id, the gather of per-lane
+episode returns into global order and the histogram all-reduce.  There is no GPU here, so each rank's
+shard is stepped by the CPU oracle (tests may); what is under test is the distributed plumbing and the
+sharding-invariance contract (results of lanes [lo,hi) do not depend on how many ranks there are)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_shard(lo, hi, steps, seed, slip):
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(77)
+    total = 3001
+    acts = rng.integers(0, 5, size=(steps, 2, total), dtype=np.int8)
+    o = Oracle(5, 4, slip, n=hi - lo, seed=seed, lane_offset=lo, autoreset=True)
+    o.reset()
+    last = np.zeros(hi - lo, np.int8); obs = None
+    for k in range(steps):
+        c = o.step(acts[k, 0, lo:hi], acts[k, 1, lo:hi])
+        fin = (c["terminated"] | c["truncated"]) == 1
+        last[fin] = c["reward"][fin]; obs = c["obs"]
+    return last, obs, o.hist.copy()
+
+
+def _worker(rank, world, port, total, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gym_soccer_littman94_amd.distributed import gather_lane_values, reduce_histogram, shard_range
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    lo, hi = shard_range(total, rank, world)
+    last, obs, hist = _run_shard(lo, hi, 130, 9, 0.2)
+    g_last = gather_lane_values(torch.from_numpy(last), total)
+    g_obs = gather_lane_values(torch.from_numpy(obs.astype(np.int32)), total)
+    g_hist = reduce_histogram(hist)
+    dist.barrier()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gathered.npz"), last=g_last.numpy(), obs=g_obs.numpy(), hist=np.array(g_hist))
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    from gym_soccer_littman94_amd.distributed import shard_range
+    for total, world in ((8388608, 8), (3001, 2), (10, 3), (7, 7)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    assert shard_range(8388608, 3, 8) == (3 * 1048576, 4 * 1048576)
+
+
+def test_two_rank_gloo_gather_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    total, world = 3001, 2                      # odd on purpose: uneven shards
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(os.path.join(str(tmp_path), "gathered.npz"))
+    last, obs, hist = _run_shard(0, total, 130, 9, 0.2)
+    np.testing.assert_array_equal(g["last"], last)
+    np.testing.assert_array_equal(g["obs"], obs)
+    np.testing.assert_array_equal(g["hist"], hist)
+    assert hist.sum() > total
