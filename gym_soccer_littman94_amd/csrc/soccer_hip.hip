@@ -34,7 +34,7 @@ struct soccer_handle {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // device buffers owned by the handle
-    uint16_t* d_lut = nullptr; uint16_t* d_nc = nullptr;
+    uint16_t* d_lut = nullptr; uint32_t* d_nc = nullptr; uint32_t* d_isd = nullptr;
     unsigned long long* d_tick = nullptr;   // two slots, 128 B apart
     unsigned long long* d_hist = nullptr;
     unsigned int* d_misuse = nullptr;
@@ -91,7 +91,7 @@ static void free_handle(soccer_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -108,9 +108,6 @@ static void set_key(soccer_handle* h, uint64_t seed) {
 
 template <int E, bool SLIP, bool LUT_LDS>
 static hipError_t raise_smem_limit(size_t bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<E, SLIP, LUT_LDS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<E, SLIP, LUT_LDS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -162,46 +159,37 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     const size_t padded = (n + 255) & ~size_t(255);
     h->state_stride = padded;
     CREATE_TRY(hipMalloc(&h->d_state, 6 * padded));
-    P.row_a = reinterpret_cast<int8_t*>(h->d_state);
-    P.col_a = reinterpret_cast<int8_t*>(h->d_state + padded);
-    P.row_b = reinterpret_cast<int8_t*>(h->d_state + 2 * padded);
-    P.col_b = reinterpret_cast<int8_t*>(h->d_state + 3 * padded);
-    P.poss = h->d_state + 4 * padded;
-    P.t = h->d_state + 5 * padded;
+    P.state = h->d_state; P.state_stride = padded;
     // every lane starts needing a reset (:140), parked on the first ISD state so the tuple is valid
-    CREATE_TRY(hipMemsetAsync(P.row_a, R.isd[0][0], padded, h->stream));
-    CREATE_TRY(hipMemsetAsync(P.col_a, R.isd[0][1], padded, h->stream));
-    CREATE_TRY(hipMemsetAsync(P.row_b, R.isd[0][2], padded, h->stream));
-    CREATE_TRY(hipMemsetAsync(P.col_b, R.isd[0][3], padded, h->stream));
-    CREATE_TRY(hipMemsetAsync(P.poss, 2 | R.isd[0][4], padded, h->stream));
-    CREATE_TRY(hipMemsetAsync(P.t, 0, padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_state, R.isd[0][0], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_state + padded, R.isd[0][1], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_state + 2 * padded, R.isd[0][2], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_state + 3 * padded, R.isd[0][3], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_state + 4 * padded, 2 | R.isd[0][4], padded, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_state + 5 * padded, 0, padded, h->stream));
 
     CREATE_TRY(hipMalloc(&h->d_lut, R.lut.size() * sizeof(uint16_t)));
-    CREATE_TRY(hipMalloc(&h->d_nc, R.next_cell.size() * sizeof(uint16_t)));
+    CREATE_TRY(hipMalloc(&h->d_nc, R.next_cell.size() * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&h->d_isd, sizeof(R.isd_words)));
+    CREATE_TRY(hipMemcpy(h->d_isd, R.isd_words, sizeof(R.isd_words), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(h->d_lut, R.lut.data(), R.lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->d_nc, R.next_cell.data(), R.next_cell.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_nc, R.next_cell.data(), R.next_cell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&h->d_tick, 256));
     CREATE_TRY(hipMemset(h->d_tick, 0, 256));
-    CREATE_TRY(hipMalloc(&h->d_hist, sizeof(unsigned long long) * kHistShards * kHistStride));
-    CREATE_TRY(hipMemset(h->d_hist, 0, sizeof(unsigned long long) * kHistShards * kHistStride));
+    CREATE_TRY(hipMalloc(&h->d_hist, sizeof(unsigned long long) * kHistSlots * kHistStride));
+    CREATE_TRY(hipMemset(h->d_hist, 0, sizeof(unsigned long long) * kHistSlots * kHistStride));
     CREATE_TRY(hipMalloc(&h->d_misuse, 128));
     CREATE_TRY(hipMemset(h->d_misuse, 0, 128));
 
-    P.lut = h->d_lut; P.next_cell = h->d_nc;
+    P.lut = h->d_lut; P.next_cell = h->d_nc; P.isd = h->d_isd;
     P.hist = h->d_hist; P.misuse = h->d_misuse;
     P.lane_offset = cfg->lane_offset;
-    P.n = n; P.H = R.H; P.W = R.W; P.HW = R.H * R.W;
+    P.first = 0; P.n = n; P.W = R.W; P.HW = R.H * R.W;
     P.lut_len = static_cast<int32_t>(R.lut.size());
     P.nc_len = static_cast<int32_t>(R.next_cell.size());
     P.max_steps = cfg->max_steps;
     P.autoreset = (cfg->flags & SOCCER_F_AUTORESET) ? 1u : 0u;
     P.isd_shift = R.n_isd == 4 ? 0u : 1u;
-    for (int i = 0; i < 4; ++i) {
-        const int k = i < R.n_isd ? i : 0;
-        P.isd_pos[i] = (uint32_t)(uint8_t)R.isd[k][0] | ((uint32_t)(uint8_t)R.isd[k][1] << 8) |
-                       ((uint32_t)(uint8_t)R.isd[k][2] << 16) | ((uint32_t)(uint8_t)R.isd[k][3] << 24);
-        P.isd_poss_obs[i] = (uint32_t)R.isd[k][4] | ((uint32_t)R.isd_obs[k] << 16);
-    }
     // slip-combination weights exactly as the reference writes them, left to right in float64 (:211-222)
     {
         volatile double s = cfg->slip_prob;   // volatile: no reassociation / contraction
@@ -217,7 +205,7 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     h->E = e ? static_cast<int>(e) : 4;
 
     // LDS budget: move/bounds table always; the observation LUT when it fits next to it
-    const size_t nc_bytes = R.next_cell.size() * sizeof(uint16_t);
+    const size_t nc_bytes = (R.next_cell.size() + kIsdWords) * sizeof(uint32_t);
     const size_t lut_bytes = R.lut.size() * sizeof(uint16_t);
     h->lut_lds = nc_bytes + lut_bytes <= 150 * 1024;
     h->smem_bytes = nc_bytes + (h->lut_lds ? lut_bytes : 0);
@@ -301,17 +289,20 @@ extern "C" int batched_reset(soccer_handle* h, const uint8_t* mask, const double
     return SOCCER_OK;
 }
 
-template <int E>
-static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& io) {
-    const int grid = grid_for(h, (P.n + E - 1) / E);
+template <bool EXPLICIT_U, bool VEC, bool SHARED>
+static void launch_step3(soccer_handle* h, const KernelParams& P, const StepIO& io) {
+    const int grid = grid_for(h, (P.n + 3) / 4);
     const dim3 g(grid), b(kBlock);
-    if (h->slip) {
-        if (h->lut_lds) hipLaunchKernelGGL((step_kernel<E, true, true>), g, b, h->smem_bytes, h->stream, P, io);
-        else hipLaunchKernelGGL((step_kernel<E, true, false>), g, b, h->smem_bytes, h->stream, P, io);
-    } else {
-        if (h->lut_lds) hipLaunchKernelGGL((step_kernel<E, false, true>), g, b, h->smem_bytes, h->stream, P, io);
-        else hipLaunchKernelGGL((step_kernel<E, false, false>), g, b, h->smem_bytes, h->stream, P, io);
-    }
+    if (h->slip) hipLaunchKernelGGL((step_kernel<true, EXPLICIT_U, VEC, SHARED>), g, b, 0, h->stream, P, io);
+    else hipLaunchKernelGGL((step_kernel<false, EXPLICIT_U, VEC, SHARED>), g, b, 0, h->stream, P, io);
+}
+static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& io, bool explicit_u, bool vec) {
+    const bool shared = ((P.lane_offset + P.first) & 3ull) == 0ull;
+    if (explicit_u) {           // facade / test path: generic instantiations only
+        if (vec && shared) launch_step3<true, true, true>(h, P, io); else launch_step3<true, false, false>(h, P, io);
+    } else if (vec && shared) launch_step3<false, true, true>(h, P, io);     // the hot instantiation
+    else if (vec) launch_step3<false, true, false>(h, P, io);
+    else launch_step3<false, false, false>(h, P, io);
 }
 
 extern "C" int batched_step_ex(soccer_handle* h, const soccer_step_args* a) {
@@ -320,21 +311,22 @@ extern "C" int batched_step_ex(soccer_handle* h, const soccer_step_args* a) {
     if (!aligned(a->u_step, 8) || !aligned(a->u_reset, 8) || !aligned(a->obs, 2) || !aligned(a->final_obs, 2))
         return fail(h, SOCCER_E_INVALID, "batched_step: u_* must be 8-byte and obs/final_obs 2-byte aligned");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    // vector width: every byte stream must be E-aligned, the uint16 streams 2E-aligned
-    int E = h->E;
-    auto ok = [&](int e) {
-        return aligned(a->act_a, e) && aligned(a->act_b, e) && aligned(a->reward, e) && aligned(a->terminated, e) &&
-               aligned(a->truncated, e) && aligned(a->prob_code, e) && aligned(a->obs, 2 * e) && aligned(a->final_obs, 2 * e);
-    };
-    while (E > 1 && !ok(E)) E = E == 4 ? 1 : E / 2;
+    // dword I/O needs every byte stream 4-aligned and the uint16 streams 8-aligned; else byte I/O
+    const bool vec = h->E != 1 && aligned(a->act_a, 4) && aligned(a->act_b, 4) && aligned(a->reward, 4) &&
+                     aligned(a->terminated, 4) && aligned(a->truncated, 4) && aligned(a->prob_code, 4) &&
+                     aligned(a->obs, 8) && aligned(a->final_obs, 8);
+    const bool explicit_u = a->u_step || a->u_reset;
     KernelParams P = h->P;
     bind_tick(h, P, 1);
     StepIO io{a->act_a, a->act_b, a->u_step, a->u_reset, a->obs, a->reward, a->terminated, a->truncated,
               a->prob_code, a->final_obs, a->last_return};
-    switch (E) {
-        case 8: launch_step<8>(h, P, io); break;
-        case 4: launch_step<4>(h, P, io); break;
-        default: launch_step<1>(h, P, io); break;
+    const unsigned long long n = h->P.n, n4 = vec ? (n & ~3ull) : 0ull;
+    if (n4) { P.first = 0; P.n = n4; launch_step(h, P, io, explicit_u, true); }
+    if (n4 < n) {               // ragged tail (or everything, when the buffers are not dword-aligned)
+        KernelParams Q = P;
+        Q.first = n4; Q.n = n - n4;
+        if (n4) Q.tick_out = nullptr;   // same tick as the main launch, which publishes it
+        launch_step(h, Q, io, explicit_u, false);
     }
     HIP_TRY(h, hipGetLastError());
     return SOCCER_OK;
@@ -382,17 +374,25 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                aligned(a->return_sum, 4 * e) && aligned(a->episode_count, 4 * e);
     };
     while (E > 1 && !ok(E)) E = E == 4 ? 1 : E / 2;
-    KernelParams P = h->P;
-    bind_tick(h, P, (uint64_t)a->n_steps);
-    RolloutIO io{a->n_steps, a->sample_actions, a->act_a, a->act_b, (long long)a->act_stride,
-                 a->obs, a->reward, a->terminated, a->truncated, (long long)a->out_stride,
-                 a->return_sum, a->episode_count};
-    switch (E) {
-        case 8: launch_rollout<8>(h, P, io); break;
-        case 4: launch_rollout<4>(h, P, io); break;
-        default: launch_rollout<1>(h, P, io); break;
+    // one launch covers at most kChunk steps (per-thread episode counters are 16 bit wide); the tick
+    // sequence of consecutive launches is contiguous, so chunking does not change any result
+    constexpr int kChunk = 4096;
+    for (int s0 = 0; s0 < a->n_steps; s0 += kChunk) {
+        const int ns = a->n_steps - s0 < kChunk ? a->n_steps - s0 : kChunk;
+        KernelParams P = h->P;
+        bind_tick(h, P, (uint64_t)ns);
+        const long long ao = (long long)s0 * a->act_stride, oo = (long long)s0 * a->out_stride;
+        RolloutIO io{ns, a->sample_actions, a->act_a ? a->act_a + ao : nullptr, a->act_b ? a->act_b + ao : nullptr,
+                     (long long)a->act_stride, a->obs ? a->obs + oo : nullptr, a->reward ? a->reward + oo : nullptr,
+                     a->terminated ? a->terminated + oo : nullptr, a->truncated ? a->truncated + oo : nullptr,
+                     (long long)a->out_stride, a->return_sum, a->episode_count};
+        switch (E) {
+            case 8: launch_rollout<8>(h, P, io); break;
+            case 4: launch_rollout<4>(h, P, io); break;
+            default: launch_rollout<1>(h, P, io); break;
+        }
+        HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipGetLastError());
     return SOCCER_OK;
 }
 
@@ -576,10 +576,10 @@ extern "C" int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* mi
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (hist) {
-        std::vector<unsigned long long> shards(kHistShards * kHistStride);
+        std::vector<unsigned long long> shards((size_t)kHistSlots * kHistStride);
         HIP_TRY(h, hipMemcpy(shards.data(), h->d_hist, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         hist[0] = hist[1] = hist[2] = 0;
-        for (int s = 0; s < kHistShards; ++s) for (int b = 0; b < 3; ++b) hist[b] += shards[s * kHistStride + b];
+        for (int s = 0; s < kHistSlots; ++s) for (int b = 0; b < 3; ++b) hist[b] += shards[(size_t)s * kHistStride + b];
     }
     if (misuse) {
         unsigned int m = 0;
@@ -592,7 +592,7 @@ extern "C" int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* mi
 extern "C" int soccer_reset_stats(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipMemsetAsync(h->d_hist, 0, sizeof(unsigned long long) * kHistShards * kHistStride, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_hist, 0, sizeof(unsigned long long) * kHistSlots * kHistStride, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_misuse, 0, 128, h->stream));
     return SOCCER_OK;
 }

@@ -29,7 +29,11 @@ struct Rules {
     std::vector<uint16_t> lut;   // [(((ra*W+ca)*H+rb)*W+cb)*2+p] -> obs index; 0 goal; 0xFFFF unreachable
     std::vector<int8_t> goal_value;
     std::vector<uint8_t> kind;   // 0 unreachable, 1 live, 2 goal
-    std::vector<uint16_t> next_cell; // [(ball*H*W + row*W+col)*5 + move] -> (new_row<<8 | new_col)
+    std::vector<uint32_t> next_cell; // [(ball*H*W + row*W+col)*5 + move] -> pos word of the cell reached
+    uint32_t isd_words[16];      // 4 x (pos A, pos B, poss | obs<<16, 0) for the kernels
+
+    // position word: low 16 bits the cell id row*W+col, high 16 bits (row<<8 | col)
+    uint32_t pos_word(int r, int c) const { return uint32_t(r * W + c) | (uint32_t((r << 8) | c) << 16); }
 
     bool goal_row(int r) const { return r >= goal_lo && r <= goal_hi; }
     bool goal_col(int c) const { return c == 0 || c == W - 1; }
@@ -89,6 +93,13 @@ struct Rules {
         }
         for (int i = 0; i < n_isd; ++i)
             isd_obs[i] = lut[flat(isd[i][0], isd[i][1], isd[i][2], isd[i][3], isd[i][4])];
+        for (int i = 0; i < 4; ++i) {
+            const int k = i < n_isd ? i : 0;
+            isd_words[4 * i + 0] = pos_word(isd[k][0], isd[k][1]);
+            isd_words[4 * i + 1] = pos_word(isd[k][2], isd[k][3]);
+            isd_words[4 * i + 2] = uint32_t(isd[k][4]) | (uint32_t(isd_obs[k]) << 16);
+            isd_words[4 * i + 3] = 0;
+        }
         // move/bounds table (:364-373)
         next_cell.assign(2 * H * W * 5, 0);
         for (int ball = 0; ball < 2; ++ball) for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c)
@@ -100,7 +111,7 @@ struct Rules {
             const bool scores = edge && goal_row(nr) && ball;           // :370
             if (edge && !scores) nc = c;                                // :371-372
             if (nc < 0 || nc > W - 1) nc = c;   // only from a goal-mouth cell; those tuples are absorbing
-            next_cell[(ball * H * W + r * W + c) * 5 + m] = static_cast<uint16_t>((nr << 8) | nc);
+            next_cell[(ball * H * W + r * W + c) * 5 + m] = pos_word(nr, nc);
         }
         return "";
     }

@@ -30,11 +30,13 @@
  * :57-58, consumed once per step and once per reset through gym's
  * categorical_sample, :395, :414):
  *   every batched_reset / batched_step call consumes one "tick" of the handle.
- *   Lane i at tick k evaluates ONE Philox4x32-10 block with
+ *   Four consecutive GLOBAL lanes share ONE Philox4x32-10 block per tick:
+ *       g = lane_offset + i,  q = g >> 2
  *       key     = (seed & 0xffffffff, seed >> 32)
- *       counter = (g & 0xffffffff, g >> 32, k & 0xffffffff, k >> 32),  g = lane_offset + i
- *   words (w0,w1) give the step uniform, words (w2,w3) the reset uniform:
- *       u = (((uint64)w_hi << 32 | w_lo) >> 11) * 2^-53        (53-bit, in [0,1))
+ *       counter = (q & 0xffffffff, q >> 32, k & 0xffffffff, (k >> 32) | purpose << 31)
+ *   (purpose 0: step/reset, 1: in-kernel action sampling; k < 2^63) and lane g takes word g & 3:
+ *       step uniform   u = (w >> 2) * 2^-30          (30-bit, in [0,1))
+ *       reset uniform  u = (w & 3) / 4               (the ISD has 2 or 4 equiprobable entries)
  *   so results depend on (seed, global lane id, tick) only — never on the
  *   device count or the launch geometry.  Callers that want to feed their own
  *   uniforms (e.g. the single-env facade, which keeps the reference's MT19937
@@ -112,8 +114,8 @@ typedef struct soccer_step_args {
 typedef struct soccer_rollout_args {
     int32_t        n_steps;     /* T >= 1 */
     int32_t        sample_actions; /* 0: read act_a/act_b; 1: draw uniform-random actions in-kernel
-                                      from a second Philox block (counter word3 bit31 set):
-                                      a = (w0*5)>>32, b = (w1*5)>>32 */
+                                      from the lane's word w of the purpose-1 Philox block:
+                                      a = ((w & 0xffff)*5)>>16, b = ((w >> 16)*5)>>16 */
     const int8_t*  act_a;       /* [T][n] (row stride act_stride) or NULL when sample_actions */
     const int8_t*  act_b;
     int64_t        act_stride;  /* elements between consecutive steps (>= n) */
@@ -142,7 +144,7 @@ int soccer_sync(soccer_handle* h);
 
 /* ---- the hot path --------------------------------------------------------------------- */
 /* reset (:410-424) for all lanes (mask NULL) or the lanes with mask[i] != 0.
- * u_reset NULL: Philox words (w2,w3).  obs (nullable) receives every lane's current observation. */
+ * u_reset NULL: the lane's Philox word.  obs (nullable) receives every lane's current observation. */
 int batched_reset(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs);
 /* step (:375-408) for all lanes with per-lane Philox randomness. */
 int batched_step(soccer_handle* h, const int8_t* act_a, const int8_t* act_b,

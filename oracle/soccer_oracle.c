@@ -292,10 +292,18 @@ void soc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-static double u53(uint32_t lo, uint32_t hi) {
-    uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;
-    return (double)m * (1.0 / 9007199254740992.0);
+/* The product's per-lane randomness (include/soccer_hip.h): one Philox block per four consecutive
+ * global lanes, q = g >> 2, counter = (q_lo, q_hi, tick_lo, tick_hi | purpose << 31); lane g uses
+ * word g & 3:  step uniform = (w >> 2) * 2^-30,  reset uniform = (w & 3) / 4. */
+static uint32_t lane_word(uint64_t seed, uint64_t g, uint64_t tick, uint32_t purpose) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint64_t q = g >> 2;
+    uint32_t ctr[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32) | (purpose << 31)};
+    uint32_t w[4]; soc_philox4x32_10(ctr, key, w);
+    return w[g & 3];
 }
+static double u_step_of(uint32_t w) { return (double)(w >> 2) * (1.0 / 1073741824.0); }
+static double u_reset_of(uint32_t w) { return (double)(w & 3u) * 0.25; }
 
 /* ---- batched semantics of the product (include/soccer_hip.h), lane by lane ------------------ */
 typedef struct {
@@ -314,21 +322,13 @@ static void do_reset_lane(const soc_oracle* o, soc_state* s, int64_t i, double u
     s->t[i] = 0;                                                    /* :423 */
 }
 
-/* reset (:410-424).  u_reset NULL -> Philox words (w2,w3) of block (lane, tick). */
+/* reset (:410-424).  u_reset NULL -> the lane's Philox word at this tick. */
 int soc_oracle_batched_reset(const soc_oracle* o, int64_t n, soc_state* s, const uint8_t* mask,
                              const double* u_reset, uint64_t seed, uint64_t lane_offset,
                              uint64_t tick, uint16_t* obs) {
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     for (int64_t i = 0; i < n; ++i) {
         if (!mask || mask[i]) {
-            double u;
-            if (u_reset) u = u_reset[i];
-            else {
-                uint64_t g = lane_offset + (uint64_t)i;
-                uint32_t ctr[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)tick, (uint32_t)(tick >> 32)};
-                uint32_t w[4]; soc_philox4x32_10(ctr, key, w);
-                u = u53(w[2], w[3]);
-            }
+            double u = u_reset ? u_reset[i] : u_reset_of(lane_word(seed, lane_offset + (uint64_t)i, tick, 0));
             do_reset_lane(o, s, i, u);
         }
         if (obs) {
@@ -350,7 +350,6 @@ int64_t soc_oracle_batched_step(const soc_oracle* o, int64_t n, soc_state* s,
                                 uint16_t* obs, int8_t* reward, uint8_t* terminated,
                                 uint8_t* truncated, double* prob, uint8_t* prob_code,
                                 uint16_t* final_obs, uint64_t* hist) {
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     int64_t misuse = 0;
     for (int64_t i = 0; i < n; ++i) {
         int32_t f = flat(o, s->row_a[i], s->col_a[i], s->row_b[i], s->col_b[i], s->poss[i] & 1);
@@ -365,13 +364,9 @@ int64_t soc_oracle_batched_step(const soc_oracle* o, int64_t n, soc_state* s,
             if (prob_code) prob_code[i] = 0;
             continue;
         }
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (!u_step || (autoreset && !u_reset)) {
-            uint64_t g = lane_offset + (uint64_t)i;
-            uint32_t ctr[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)tick, (uint32_t)(tick >> 32)};
-            soc_philox4x32_10(ctr, key, w);
-        }
-        double u = u_step ? u_step[i] : u53(w[0], w[1]);
+        uint32_t w = 0;
+        if (!u_step || (autoreset && !u_reset)) w = lane_word(seed, lane_offset + (uint64_t)i, tick, 0);
+        double u = u_step ? u_step[i] : u_step_of(w);
         const trans_list* tl = &o->P[(size_t)f * 25 + act_a[i] * 5 + act_b[i]];   /* :394 */
         int k = categorical_sample(tl->p, tl->n, u);                              /* :395 */
         int32_t ns = tl->ns[k];                                                   /* :396 */
@@ -396,7 +391,7 @@ int64_t soc_oracle_batched_step(const soc_oracle* o, int64_t n, soc_state* s,
         }
         if (need && hist) hist[tl->r[k] + 1] += 1;
         if (need && autoreset) {
-            double ur = u_reset ? u_reset[i] : u53(w[2], w[3]);
+            double ur = u_reset ? u_reset[i] : u_reset_of(w);
             do_reset_lane(o, s, i, ur);
             int32_t f2 = flat(o, s->row_a[i], s->col_a[i], s->row_b[i], s->col_b[i], s->poss[i] & 1);
             ob = obs_of(o, f2);
@@ -406,17 +401,13 @@ int64_t soc_oracle_batched_step(const soc_oracle* o, int64_t n, soc_state* s,
     return misuse;
 }
 
-/* uniform-random joint action of the in-kernel sampler: second Philox block, counter word3 bit31
- * set; a = (w0*5)>>32, b = (w1*5)>>32 (include/soccer_hip.h, soccer_rollout_args). */
+/* uniform-random joint action of the in-kernel sampler: the lane's word of the purpose-1 block;
+ * a = ((w & 0xffff) * 5) >> 16, b = ((w >> 16) * 5) >> 16 (include/soccer_hip.h, soccer_rollout_args). */
 void soc_oracle_sample_actions(int64_t n, uint64_t seed, uint64_t lane_offset, uint64_t tick,
                                int8_t* act_a, int8_t* act_b) {
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     for (int64_t i = 0; i < n; ++i) {
-        uint64_t g = lane_offset + (uint64_t)i;
-        uint32_t ctr[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)tick,
-                           (uint32_t)(tick >> 32) | 0x80000000u};
-        uint32_t w[4]; soc_philox4x32_10(ctr, key, w);
-        act_a[i] = (int8_t)(((uint64_t)w[0] * 5u) >> 32);
-        act_b[i] = (int8_t)(((uint64_t)w[1] * 5u) >> 32);
+        uint32_t w = lane_word(seed, lane_offset + (uint64_t)i, tick, 1);
+        act_a[i] = (int8_t)(((w & 0xffffu) * 5u) >> 16);
+        act_b[i] = (int8_t)(((w >> 16) * 5u) >> 16);
     }
 }
