@@ -45,7 +45,7 @@ struct soccer_handle {
     size_t stage_bytes = 0;
     int tick_slot = 0;                      // slot the NEXT launch reads
     uint64_t tick = 0;                      // host mirror of the device tick
-    bool slip = false, lut_lds = true;
+    bool slip = false, lut_lds = false;
     size_t smem_bytes = 0;
     int E = 4;
     int grid_cap = 2048;
@@ -168,11 +168,9 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     CREATE_TRY(hipMemsetAsync(h->d_state + 4 * padded, 2 | R.isd[0][4], padded, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_state + 5 * padded, 0, padded, h->stream));
 
-    CREATE_TRY(hipMalloc(&h->d_lut, R.lut.size() * sizeof(uint16_t)));
     CREATE_TRY(hipMalloc(&h->d_nc, R.next_cell.size() * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&h->d_isd, sizeof(R.isd_words)));
     CREATE_TRY(hipMemcpy(h->d_isd, R.isd_words, sizeof(R.isd_words), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->d_lut, R.lut.data(), R.lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(h->d_nc, R.next_cell.data(), R.next_cell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&h->d_tick, 256));
     CREATE_TRY(hipMemset(h->d_tick, 0, 256));
@@ -181,11 +179,10 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     CREATE_TRY(hipMalloc(&h->d_misuse, 128));
     CREATE_TRY(hipMemset(h->d_misuse, 0, 128));
 
-    P.lut = h->d_lut; P.next_cell = h->d_nc; P.isd = h->d_isd;
+    P.next_cell = h->d_nc; P.isd = h->d_isd;
     P.hist = h->d_hist; P.misuse = h->d_misuse;
     P.lane_offset = cfg->lane_offset;
-    P.first = 0; P.n = n; P.W = R.W; P.HW = R.H * R.W;
-    P.lut_len = static_cast<int32_t>(R.lut.size());
+    P.first = 0; P.n = n; P.W = R.W; P.HW = R.H * R.W; P.HW5 = 5 * R.H * R.W;
     P.nc_len = static_cast<int32_t>(R.next_cell.size());
     P.max_steps = cfg->max_steps;
     P.autoreset = (cfg->flags & SOCCER_F_AUTORESET) ? 1u : 0u;
@@ -204,9 +201,17 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     h->slip = cfg->slip_prob != 0.0;
     h->E = e ? static_cast<int>(e) : 4;
 
-    // LDS budget: move/bounds table always; the observation LUT when it fits next to it
+    // Observation table (uint16 index < 65535 bounds it to a few hundred KB): global for the step kernel,
+    // staged into LDS by the rollout / reset kernels when it fits next to the move/bounds table.
     const size_t nc_bytes = (R.next_cell.size() + kIsdWords) * sizeof(uint32_t);
     const size_t lut_bytes = R.lut.size() * sizeof(uint16_t);
+    if (nc_bytes > 150 * 1024) {
+        free_handle(h);
+        return fail(nullptr, SOCCER_E_INVALID, "pitch too large: the move/bounds table (%zu bytes) must fit the 160 KB LDS", nc_bytes);
+    }
+    CREATE_TRY(hipMalloc(&h->d_lut, lut_bytes));
+    CREATE_TRY(hipMemcpy(h->d_lut, R.lut.data(), lut_bytes, hipMemcpyHostToDevice));
+    P.lut = h->d_lut; P.lut_len = static_cast<int32_t>(R.lut.size());
     h->lut_lds = nc_bytes + lut_bytes <= 150 * 1024;
     h->smem_bytes = nc_bytes + (h->lut_lds ? lut_bytes : 0);
     if (h->smem_bytes > 48 * 1024) {

@@ -34,7 +34,7 @@ struct KernelParams {
     unsigned long long state_stride;
     // rule tables in global memory (staged to LDS)
     const uint16_t* lut;                  // [lut_len] observation index per state tuple
-    const uint32_t* next_cell;            // [2*H*W*5] (row<<8|col)<<16 | (row*W+col) of the cell reached
+    const uint32_t* next_cell;            // [2][H*W][5]: (has_ball, cell, move) -> (row<<8|col)<<16 | (row*W+col) reached
     const uint32_t* isd;                  // [kIsdWords]
     // randomness
     const unsigned long long* tick_in;    // device tick slot read by this launch
@@ -47,7 +47,7 @@ struct KernelParams {
     // geometry / constants
     unsigned long long first;             // first lane (within the handle) this launch covers
     unsigned long long n;                 // number of lanes this launch covers
-    int32_t W, HW, lut_len, nc_len;
+    int32_t W, HW, HW5, nc_len, lut_len;   // HW5 = 5*H*W
     int32_t max_steps;
     uint32_t autoreset;
     uint32_t isd_shift;                   // 2 - log2(n_isd): index = two random bits >> isd_shift
@@ -110,12 +110,13 @@ __device__ __forceinline__ double sane_uniform(double u) { return ((u >= 0.0) &&
 
 // ---- LDS-resident rule tables ------------------------------------------------------------------
 struct Tables {
-    const uint16_t* lut;    // LDS (or global when it does not fit)
-    const uint32_t* nc;     // LDS
-    const uint32_t* isd;    // LDS
+    const uint16_t* lut;    // observation index per tuple
+    const uint32_t* nc;     // move/bounds table (LDS in the rollout/reset kernels, global in the step kernel)
+    const uint32_t* isd;    // initial-state entries
 };
 
-// LDS layout (dwords): [0, kIsdWords) ISD, [kIsdWords, kIsdWords + nc_len) move/bounds table, then the LUT
+// LDS layout (dwords): [0, kIsdWords) ISD, [kIsdWords, kIsdWords + nc_len) move/bounds table, then
+// (LUT_LDS) the observation table
 template <bool LUT_LDS>
 __device__ __forceinline__ Tables stage_tables(const KernelParams& P, uint32_t* smem) {
     if (threadIdx.x < kIsdWords) smem[threadIdx.x] = P.isd[threadIdx.x];
@@ -130,7 +131,7 @@ __device__ __forceinline__ Tables stage_tables(const KernelParams& P, uint32_t* 
         for (int i = threadIdx.x; i < lut_dw; i += kBlock) lut[i] = src[i];
         T.lut = reinterpret_cast<const uint16_t*>(lut);
     } else {
-        T.lut = P.lut;
+        T.lut = P.lut;                                    // global (L1/L2)
     }
     __syncthreads();
     return T;
@@ -162,8 +163,12 @@ __device__ __forceinline__ uint32_t make_pos(uint32_t row, uint32_t col, int W) 
 __device__ __forceinline__ uint32_t cell_of(uint32_t pos) { return pos & 0xffffu; }
 __device__ __forceinline__ uint32_t col_of(uint32_t pos) { return (pos >> 16) & 0xffu; }
 
+// Observation index of a tuple: one gather from the per-tuple table (goal tuples hold 0, :493-494).
+// A closed form exists — obs = 1 + 2*(iA*(NI-1) + iB - (iB > iA)) + p over interior-cell indices, see
+// Rules::build, which checks the table against it — but the kernels are VALU-bound and the gather
+// rides the memory pipe: the ~12 extra vector instructions measured 4 % slower per step.
 __device__ __forceinline__ uint32_t obs_of(const Tables& T, const KernelParams& P, uint32_t A, uint32_t B, uint32_t p) {
-    return T.lut[mad24(cell_of(A), (uint32_t)P.HW, cell_of(B)) * 2u + p];
+    return T.lut[(mad24(cell_of(A), (uint32_t)P.HW, cell_of(B)) << 1) | p];
 }
 
 // slipped move of an action: variant 0 intended, 1/2 the two orthogonals (:205-206)
@@ -183,8 +188,8 @@ struct Resolved { uint32_t kind, nA, nB; };
 __device__ __forceinline__ Resolved resolve(const Tables& T, const KernelParams& P, uint32_t A, uint32_t B,
                                             uint32_t p, uint32_t aa, uint32_t ab, uint32_t mvA, uint32_t mvB) {
     const uint32_t ballA = p ^ 1u, ballB = p;
-    const uint32_t nA = T.nc[mad24(mad24(ballA, (uint32_t)P.HW, cell_of(A)), 5u, mvA)];
-    const uint32_t nB = T.nc[mad24(mad24(ballB, (uint32_t)P.HW, cell_of(B)), 5u, mvB)];
+    const uint32_t nA = T.nc[mad24(ballA, (uint32_t)P.HW5, mad24(cell_of(A), 5u, mvA))];
+    const uint32_t nB = T.nc[mad24(ballB, (uint32_t)P.HW5, mad24(cell_of(B), 5u, mvB))];
     const bool e1 = nA == B, e2 = nB == A, sA = nA == A, sB = nB == B;
     const bool swap = e1 & e2;                                                         // :315-322
     const bool stander = (e1 & (ab == 0u)) | (e2 & (aa == 0u));                      // :330-331
@@ -270,7 +275,7 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
     const uint32_t trunc = tt >= (uint32_t)P.max_steps ? 1u : 0u;      // :404
     const uint32_t done = goal_now ? 1u : 0u;
     const uint32_t need = done | trunc;                                 // :406
-    const uint32_t ob_step = obs_of(T, P, sel.A, sel.B, sel.p);         // :397 (goal tuples map to 0)
+    const uint32_t ob_step = obs_of(T, P, sel.A, sel.B, sel.p);      // :397 (goal tuples map to 0)
     out.obs = ob_step; out.final_obs = ob_step; out.reward = reward; out.term = done; out.trunc = trunc;
     out.code = cls * 3u + sel.kcode; out.finished = need;
     Lane L{sel.A, sel.B, sel.p, need, tt};
@@ -418,21 +423,28 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
            (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
+// EARLY: fetch the wave's slot at kernel entry so the load's latency hides under the whole kernel (the
+// single-step kernel, where every microsecond of tail counts); otherwise read-modify-write at exit
+// (the rollout kernel, which would pay 6 live VGPRs — and an occupancy step — for nothing).
+template <bool EARLY>
 struct HistAcc {
     uint32_t fp;            // this thread's finished episodes: all | (return +1) << 16
     uint32_t ng;            // ... with return -1
-    ulonglong2 old01; unsigned long long old2;   // the wave's slot, fetched at kernel entry (lane 0)
+    ulonglong2 old01; unsigned long long old2;   // EARLY only: the wave's slot as of kernel entry (lane 0)
     __device__ __forceinline__ unsigned long long* slot(const KernelParams& P) const {
-        const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         return P.hist + (size_t)(wave % kHistSlots) * kHistStride;
     }
-    // Every wave of a launch owns one slot (launches are stream-ordered), so a plain load at entry and
-    // a plain store at exit accumulate without atomics; the load's latency hides under the whole kernel.
+    // Every wave of a launch owns one slot and launches are stream-ordered, so plain loads and stores
+    // accumulate without atomics.
     __device__ __forceinline__ void init(const KernelParams& P) {
-        fp = 0u; ng = 0u; old01 = make_ulonglong2(0ull, 0ull); old2 = 0ull;
-        if ((threadIdx.x & 63u) == 0u) {
-            const unsigned long long* h = slot(P);
-            old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2];
+        fp = 0u; ng = 0u;
+        if (EARLY) {
+            old01 = make_ulonglong2(0ull, 0ull); old2 = 0ull;
+            if ((threadIdx.x & 63u) == 0u) {
+                const unsigned long long* h = slot(P);
+                old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2];
+            }
         }
     }
     __device__ __forceinline__ void add(uint32_t finished, int32_t reward) {
@@ -445,6 +457,7 @@ struct HistAcc {
         const uint32_t tot = wave_sum(fp & 0xffffu), pos = wave_sum(fp >> 16), neg = wave_sum(ng);
         if ((threadIdx.x & 63u) == 0u && tot) {
             unsigned long long* h = slot(P);
+            if (!EARLY) { old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2]; }
             *reinterpret_cast<ulonglong2*>(h) = make_ulonglong2(old01.x + neg, old01.y + (tot - pos - neg));
             h[2] = old2 + pos;
         }
@@ -514,16 +527,16 @@ __device__ __forceinline__ void store4h(uint16_t* base, unsigned long long i, in
 // EXPLICIT_U: caller-supplied uniforms (u_step / u_reset) may replace the Philox draw.
 // The hot instantiation <SLIP=false, EXPLICIT_U=false, VEC=true, SHARED=true> carries none of the
 // fallback code.
-template <bool SLIP, bool EXPLICIT_U, bool VEC, bool SHARED>
-__global__ __launch_bounds__(kBlock) void step_kernel(const KernelParams P, const StepIO IO) {
+template <bool SLIP, bool EXPLICIT_U, bool VEC, bool SHARED, int UNROLL = 1, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const StepIO IO) {
     const unsigned long long groups = (P.n + 3) >> 2;
-    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
     const unsigned long long tick = *P.tick_in;                 // scalar load
     if (P.tick_out) publish_tick(P, tick, 1ull);
-    HistAcc hist; hist.init(P);
+    HistAcc<true> hist; hist.init(P);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
     bool mis = false;
-    for (unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    for (unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; g < groups; g += stride) {
         const unsigned long long i0 = P.first + (g << 2);
         const int cnt = VEC ? 4 : ((P.n - (g << 2)) < 4ull ? (int)(P.n - (g << 2)) : 4);
         const uint8_t* sp = P.state;
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KernelParams P, cons
         if (SHARED && need_philox) blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
         uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0;
         uint32_t o_rew = 0, o_term = 0, o_trunc = 0, o_code = 0, o_lo = 0, o_hi = 0, f_lo = 0, f_hi = 0, fin_mask = 0;
-#pragma unroll 1
+#pragma unroll UNROLL
         for (int j = 0; j < cnt; ++j) {
             uint32_t w = j & 2 ? (j & 1 ? blk.w[3] : blk.w[2]) : (j & 1 ? blk.w[1] : blk.w[0]);
             if (!SHARED && need_philox) {
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KernelParams P, con
 template <int E, bool SLIP>
 __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParams& P, const RolloutIO& IO,
                                               unsigned long long i0, unsigned long long tick0,
-                                              HistAcc& hist, bool& any_misuse) {
+                                              HistAcc<false>& hist, bool& any_misuse) {
     LaneVec<E> S; S.load(P, i0);
     int32_t ret[E], eps[E];
 #pragma unroll
@@ -677,7 +690,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
 template <int E, bool SLIP, bool LUT_LDS>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const KernelParams P, const RolloutIO IO) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    HistAcc hist; hist.init(P);
+    HistAcc<false> hist; hist.init(P);
     const Tables T = stage_tables<LUT_LDS>(P, smem);
     const unsigned long long tick0 = *P.tick_in;
     publish_tick(P, tick0, (unsigned long long)IO.n_steps);

@@ -29,7 +29,7 @@ struct Rules {
     std::vector<uint16_t> lut;   // [(((ra*W+ca)*H+rb)*W+cb)*2+p] -> obs index; 0 goal; 0xFFFF unreachable
     std::vector<int8_t> goal_value;
     std::vector<uint8_t> kind;   // 0 unreachable, 1 live, 2 goal
-    std::vector<uint32_t> next_cell; // [(ball*H*W + row*W+col)*5 + move] -> pos word of the cell reached
+    std::vector<uint32_t> next_cell; // [(has_ball*H*W + row*W+col)*5 + move] -> pos word of the cell reached
     uint32_t isd_words[16];      // 4 x (pos A, pos B, poss | obs<<16, 0) for the kernels
 
     // position word: low 16 bits the cell id row*W+col, high 16 bits (row<<8 | col)
@@ -72,6 +72,20 @@ struct Rules {
             if (next_id > 0xFFFE) return "pitch too large (observation index must fit uint16)";
         }
         nS = static_cast<int>(next_id);
+        // Self-check against the closed form of the numbering: a tuple is live exactly when both players
+        // stand on distinct interior cells; with i = row*(W-2) + col-1 and NI = H*(W-2) interior cells,
+        // index = 1 + 2*(iA*(NI-1) + iB - (iB > iA)) + p.
+        {
+            const int NI = H * (W - 2);
+            if (nS != NI * (NI - 1) * 2 + 1) return "internal error: state numbering";
+            for (int ra = 0; ra < H; ++ra) for (int ca = 1; ca < W - 1; ++ca)
+            for (int rb = 0; rb < H; ++rb) for (int cb = 1; cb < W - 1; ++cb) for (int p = 0; p < 2; ++p) {
+                if (ra == rb && ca == cb) continue;
+                const int ia = ra * (W - 2) + ca - 1, ib = rb * (W - 2) + cb - 1;
+                if (lut[flat(ra, ca, rb, cb, p)] != 1 + 2 * (ia * (NI - 1) + ib - (ib > ia ? 1 : 0)) + p)
+                    return "internal error: state numbering";
+            }
+        }
         // initial state distribution (:146-165): A two columns from its goal line, B likewise
         const int col_a = 2, col_b = W - 3;
         const int n_goal_rows = goal_hi - goal_lo + 1;

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_tick(const KernelParams P, const StepIO
 __global__ __launch_bounds__(256) void k_stage(const KernelParams P, const StepIO IO) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const Tables T = stage_tables<true>(P, smem);
-    if (T.lut[threadIdx.x] == 0x1234 && IO.obs) IO.obs[0] = 1;   // keep it live
+    if (T.nc[threadIdx.x] == 0x1234 && IO.obs) IO.obs[0] = 1;   // keep it live
 }
 
 template <int E, bool STAGE>
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_copy(const KernelParams P, const StepIO
     if (i0 + E > P.n) return;
     RawState<E> raw; PackB<E> aa, ab;
     raw.load(P, i0); aa.load(IO.act_a, i0); ab.load(IO.act_b, i0);
-    if (STAGE) { const Tables T = stage_tables<true>(P, smem); if (T.lut[threadIdx.x] == 0x1234) aa.w[0] ^= 1; }
+    if (STAGE) { const Tables T = stage_tables<true>(P, smem); if (T.nc[threadIdx.x] == 0x1234) aa.w[0] ^= 1; }
     LaneVec<E> S; S.unpack(P, raw);
     PackB<E> o1, o2, o3; PackH<E> oh; o1.clear(); o2.clear(); o3.clear(); oh.clear();
 #pragma unroll
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_step_rolled(const KernelParams P, const
         aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0); ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
     }
     const unsigned long long tick = *P.tick_in;
-    HistAcc hist; hist.init(P);
+    HistAcc<true> hist; hist.init(P);
     Tables T;
     if (USE_LDS) T = stage_tables<true>(P, smem);
     else { T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd; if (HIST) __syncthreads(); }
@@ -121,10 +121,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_tick, 256)); CK(hipMemset(d_tick, 0, 256));
     CK(hipMalloc(&d_hist, 8 * kHistSlots * kHistStride)); CK(hipMemset(d_hist, 0, 8 * kHistSlots * kHistStride));
     CK(hipMalloc(&d_mis, 128)); CK(hipMemset(d_mis, 0, 128));
-    P.state = d_state; P.state_stride = padded; P.lut = d_lut; P.next_cell = d_nc; P.isd = d_isd;
+    P.state = d_state; P.state_stride = padded; P.lut = d_lut; P.lut_len = (int)R.lut.size(); P.next_cell = d_nc; P.isd = d_isd;
     P.tick_in = d_tick; P.tick_out = d_tick + 16; P.key0 = 1; P.key1 = 2; P.lane_offset = 0;
-    P.hist = d_hist; P.misuse = d_mis; P.first = 0; P.n = N; P.W = R.W; P.HW = R.H * R.W;
-    P.lut_len = (int)R.lut.size(); P.nc_len = (int)R.next_cell.size(); P.max_steps = 100; P.autoreset = 1; P.isd_shift = 0;
+    P.hist = d_hist; P.misuse = d_mis; P.first = 0; P.n = N; P.W = R.W; P.HW = R.H * R.W; P.HW5 = 5 * R.H * R.W;
+    P.nc_len = (int)R.next_cell.size(); P.max_steps = 100; P.autoreset = 1; P.isd_shift = 0;
     P.w[0] = 1; P.w[1] = P.w[2] = P.w[3] = 0;
     const size_t smem = (kIsdWords + R.next_cell.size()) * 4 + R.lut.size() * 2;
     // actions: T rows cycled
@@ -153,6 +153,11 @@ int main(int argc, char** argv) {
     add("rolled E4 global hist    ", [&] { hipLaunchKernelGGL((k_step_rolled<false, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step (no last_ret)", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step + last_return", [&] { StepIO io = io_for(step); io.last_return = d_last; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io); });
+    add("PRODUCT step unroll 2     ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 2>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("PRODUCT step unroll 4     ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 4>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("PRODUCT step 2048 x 128   ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 128>), dim3(2048), dim3(128), 0, st, P, io_for(step)); });
+    add("PRODUCT step  512 x 512   ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 512>), dim3(512), dim3(512), 0, st, P, io_for(step)); });
+    add("PRODUCT step  256 x 1024  ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 1024>), dim3(256), dim3(1024), 0, st, P, io_for(step)); });
     add("PRODUCT step bytes (VEC=0)", [&] { hipLaunchKernelGGL((step_kernel<false, false, false, false>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("rolled E4 global nohist  ", [&] { hipLaunchKernelGGL((k_step_rolled<false, false>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     // reset state so `step` variants act on valid tuples: run the real reset first
