@@ -183,13 +183,14 @@ enum : uint32_t { K_MOVE = 0, K_FLIP = 1, K_COIN = 2, K_FOUR = 3 };
 
 struct Resolved { uint32_t kind, nA, nB; };
 
-// _get_next_state (:296-362) for a live tuple.  aa/ab: ORIGINAL actions (the NOOP tests);
-// mvA/mvB: the (possibly slipped) moves.
-__device__ __forceinline__ Resolved resolve(const Tables& T, const KernelParams& P, uint32_t A, uint32_t B,
-                                            uint32_t p, uint32_t aa, uint32_t ab, uint32_t mvA, uint32_t mvB) {
-    const uint32_t ballA = p ^ 1u, ballB = p;
-    const uint32_t nA = T.nc[mad24(ballA, (uint32_t)P.HW5, mad24(cell_of(A), 5u, mvA))];
-    const uint32_t nB = T.nc[mad24(ballB, (uint32_t)P.HW5, mad24(cell_of(B), 5u, mvB))];
+// the cell a player reaches with one move (_next_cell :364-373, via the move/bounds table)
+__device__ __forceinline__ uint32_t moved(const Tables& T, const KernelParams& P, uint32_t pos, uint32_t has_ball, uint32_t mv) {
+    return T.nc[mad24(has_ball, (uint32_t)P.HW5, mad24(cell_of(pos), 5u, mv))];
+}
+
+// _get_next_state (:296-362) for a live tuple, given the cells nA / nB the two (possibly slipped) moves
+// reach.  aa/ab are the ORIGINAL actions: the reference's NOOP tests use those, not the moves.
+__device__ __forceinline__ Resolved classify(uint32_t A, uint32_t B, uint32_t nA, uint32_t nB, uint32_t aa, uint32_t ab) {
     const bool e1 = nA == B, e2 = nB == A, sA = nA == A, sB = nB == B;
     const bool swap = e1 & e2;                                                         // :315-322
     const bool stander = (e1 & (ab == 0u)) | (e2 & (aa == 0u));                      // :330-331
@@ -229,23 +230,35 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
     if (!SLIP) {
         // single surviving combination, weight 1.0 (:226-227): list probabilities are 1, .5/.5 or .25x4,
         // so the sampled index is floor(2u) / floor(4u)
-        const Resolved R = resolve(T, P, A, B, p, aa, ab, aa, ab);
+        const Resolved R = classify(A, B, moved(T, P, A, p ^ 1u, aa), moved(T, P, B, p, ab), aa, ab);
         const uint32_t k = R.kind == K_COIN ? (d.top2 >> 1) : d.top2;
         sel = pick(A, B, p, R, k);
     } else {
         constexpr int VA[9] = {0, 0, 0, 1, 2, 1, 1, 2, 2};
         constexpr int VB[9] = {0, 1, 2, 0, 0, 1, 2, 1, 2};
         constexpr int CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+        // each player has only three distinct moves (intended + two orthogonals): 6 table reads serve
+        // all nine combinations
+        uint32_t cellA[3], cellB[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            cellA[v] = moved(T, P, A, p ^ 1u, slip_move(aa, v));
+            cellB[v] = moved(T, P, B, p, slip_move(ab, v));
+        }
+        // Walk the list exactly as categorical_sample does — sequential float64 running sum over the
+        // combinations in reference order, each contributing 1, 2 or 4 equal entries — but only record
+        // WHICH entry (combination c, outcome k) is the first to exceed u; the outcome itself is built
+        // once, after the loop.
         double acc = 0.0;
-        bool found = false, have_first = false;
-        Outcome first = Outcome{A, B, p, 0u}; uint32_t first_cls = 0;
-        sel = first;
+        bool found = false;
+        uint32_t sel_c = 0u, sel_k = 0u;
+        int first_c = -1;                                               // wave-uniform (weights are)
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
             const double wgt = P.w[CLS[c]];
             if (wgt == 0.0) continue;                                   // uniform branch (:226-227)
-            const Resolved R = resolve(T, P, A, B, p, aa, ab, slip_move(aa, VA[c]), slip_move(ab, VB[c]));
-            const uint32_t kind = in_goal ? (uint32_t)K_MOVE : R.kind;
+            if (first_c < 0) first_c = c;
+            const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cellA[VA[c]], cellB[VB[c]], aa, ab).kind;
             const uint32_t n = kind == K_COIN ? 2u : (kind == K_FOUR ? 4u : 1u);
             const double q = wgt * (n == 1u ? 1.0 : (n == 2u ? 0.5 : 0.25));   // :241
             const double a1 = acc + q, a2 = a1 + q, a3 = a2 + q, a4 = a3 + q;   // sequential cumsum
@@ -253,17 +266,20 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
             const uint32_t k = (d.u >= a1 ? 1u : 0u) + (((n > 1u) & (d.u >= a2)) ? 1u : 0u) +
                                (((n > 2u) & (d.u >= a3)) ? 1u : 0u);
             const bool here = !found & (end > d.u);
-            const Outcome o = pick(A, B, p, R, here ? k : 0u);
-            const bool take_first = !have_first;
-            sel.A = here ? o.A : sel.A; sel.B = here ? o.B : sel.B; sel.p = here ? o.p : sel.p;
-            sel.kcode = here ? o.kcode : sel.kcode; cls = here ? (uint32_t)CLS[c] : cls;
-            first.A = take_first ? o.A : first.A; first.B = take_first ? o.B : first.B;
-            first.p = take_first ? o.p : first.p; first.kcode = take_first ? o.kcode : first.kcode;
-            first_cls = take_first ? (uint32_t)CLS[c] : first_cls;
-            found |= here; have_first = true;
+            sel_c = here ? (uint32_t)c : sel_c; sel_k = here ? k : sel_k;
+            found |= here;
             acc = end;
         }
-        if (!found) { sel = first; cls = first_cls; }                   // argmax of all-False is 0
+        if (!found) { sel_c = (uint32_t)(first_c < 0 ? 0 : first_c); sel_k = 0u; }   // argmax of all-False is 0
+        // VA / VB / CLS of the selected combination, 2 bits each
+        constexpr uint32_t VA2 = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
+        constexpr uint32_t VB2 = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
+        constexpr uint32_t CL2 = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
+        const uint32_t va = (VA2 >> (2u * sel_c)) & 3u, vb = (VB2 >> (2u * sel_c)) & 3u;
+        cls = (CL2 >> (2u * sel_c)) & 3u;
+        const uint32_t sA_ = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
+        const uint32_t sB_ = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
+        sel = pick(A, B, p, classify(A, B, sA_, sB_, aa, ab), sel_k);
     }
     sel.A = in_goal ? A : sel.A; sel.B = in_goal ? B : sel.B; sel.p = in_goal ? p : sel.p;
     sel.kcode = in_goal ? 0u : sel.kcode;

@@ -102,6 +102,72 @@ __global__ __launch_bounds__(256) void k_step_rolled(const KernelParams P, const
     if (HIST) hist.flush(P);
 }
 
+
+// two groups per thread, software pipelined: all 16 loads up front, compute A, store A, compute B, store B
+struct G4 { uint32_t ra, ca, rb, cb, ps, tt, aa, ab; };
+__device__ __forceinline__ G4 load_g4(const KernelParams& P, const StepIO& IO, unsigned long long i0) {
+    G4 g; const uint8_t* s = P.state;
+    g.ra = *reinterpret_cast<const uint32_t*>(s + i0); g.ca = *reinterpret_cast<const uint32_t*>(s + P.state_stride + i0);
+    g.rb = *reinterpret_cast<const uint32_t*>(s + 2 * P.state_stride + i0); g.cb = *reinterpret_cast<const uint32_t*>(s + 3 * P.state_stride + i0);
+    g.ps = *reinterpret_cast<const uint32_t*>(s + 4 * P.state_stride + i0); g.tt = *reinterpret_cast<const uint32_t*>(s + 5 * P.state_stride + i0);
+    g.aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0); g.ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
+    return g;
+}
+template <bool HIST>
+__device__ __forceinline__ void do_g4(const Tables& T, const KernelParams& P, const StepIO& IO, unsigned long long i0,
+                                      unsigned long long tick, G4 g, HistAcc<true>& hist, bool& mis) {
+    const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
+    uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = j & 2 ? (j & 1 ? blk.w[3] : blk.w[2]) : (j & 1 ? blk.w[1] : blk.w[0]);
+        Lane L;
+        L.A = make_pos(g.ra & 0xffu, g.ca & 0xffu, P.W); L.B = make_pos(g.rb & 0xffu, g.cb & 0xffu, P.W);
+        L.p = g.ps & 1u; L.need = (g.ps >> 1) & 1u; L.t = g.tt & 0xffu;
+        StepResult R;
+        mis |= lane_step<false>(T, P, L, g.aa & 0xffu, g.ab & 0xffu, draw_from_word(w), R);
+        g.ra >>= 8; g.ca >>= 8; g.rb >>= 8; g.cb >>= 8; g.ps >>= 8; g.tt >>= 8; g.aa >>= 8; g.ab >>= 8;
+        nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
+        nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
+        nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
+        o_rew = __builtin_amdgcn_alignbyte((uint32_t)R.reward & 0xffu, o_rew, 1);
+        o_term = __builtin_amdgcn_alignbyte(R.term, o_term, 1); o_trunc = __builtin_amdgcn_alignbyte(R.trunc, o_trunc, 1);
+        o_lo = __builtin_amdgcn_alignbit(o_hi, o_lo, 16); o_hi = (o_hi >> 16) | (R.obs << 16);
+        if (HIST) hist.add(R.finished, R.reward);
+    }
+    uint8_t* s = P.state;
+    *reinterpret_cast<uint32_t*>(s + i0) = nra; *reinterpret_cast<uint32_t*>(s + P.state_stride + i0) = nca;
+    *reinterpret_cast<uint32_t*>(s + 2 * P.state_stride + i0) = nrb; *reinterpret_cast<uint32_t*>(s + 3 * P.state_stride + i0) = ncb;
+    *reinterpret_cast<uint32_t*>(s + 4 * P.state_stride + i0) = nps; *reinterpret_cast<uint32_t*>(s + 5 * P.state_stride + i0) = ntt;
+    *reinterpret_cast<uint2*>(IO.obs + i0) = make_uint2(o_lo, o_hi);
+    *reinterpret_cast<uint32_t*>(IO.reward + i0) = o_rew; *reinterpret_cast<uint32_t*>(IO.terminated + i0) = o_term;
+    *reinterpret_cast<uint32_t*>(IO.truncated + i0) = o_trunc;
+}
+template <bool HIST, int NG>
+__global__ __launch_bounds__(256) void k_step_pipe(const KernelParams P, const StepIO IO) {
+    const unsigned long long groups = P.n >> 2;
+    const unsigned long long per = groups / NG;            // assumes divisibility (lab only)
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (g0 >= per) return;
+    const unsigned long long tick = *P.tick_in;
+    publish_tick(P, tick, 1ull);
+    HistAcc<true> hist; hist.init(P);
+    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
+    bool mis = false;
+    G4 g[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) g[k] = load_g4(P, IO, (g0 + k * per) << 2);
+#pragma unroll 1
+    for (int k = 0; k < NG; ++k) {
+        G4 cur = g[0];
+#pragma unroll
+        for (int m = 0; m + 1 < NG; ++m) g[m] = g[m + 1];
+        do_g4<HIST>(T, P, IO, (g0 + k * per) << 2, tick, cur, hist, mis);
+    }
+    if (mis) *P.misuse = 1u;
+    if (HIST) hist.flush(P);
+}
+
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; };
 #include <functional>
 
@@ -153,6 +219,10 @@ int main(int argc, char** argv) {
     add("rolled E4 global hist    ", [&] { hipLaunchKernelGGL((k_step_rolled<false, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step (no last_ret)", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step + last_return", [&] { StepIO io = io_for(step); io.last_return = d_last; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io); });
+    add("pipe2 hist               ", [&] { hipLaunchKernelGGL((k_step_pipe<true, 2>), dim3(512), dim3(256), 0, st, P, io_for(step)); });
+    add("pipe2 nohist             ", [&] { hipLaunchKernelGGL((k_step_pipe<false, 2>), dim3(512), dim3(256), 0, st, P, io_for(step)); });
+    add("pipe4 hist               ", [&] { hipLaunchKernelGGL((k_step_pipe<true, 4>), dim3(256), dim3(256), 0, st, P, io_for(step)); });
+    add("pipe1 hist (ref)         ", [&] { hipLaunchKernelGGL((k_step_pipe<true, 1>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step unroll 2     ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 2>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step unroll 4     ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 4>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step 2048 x 128   ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 128>), dim3(2048), dim3(128), 0, st, P, io_for(step)); });
