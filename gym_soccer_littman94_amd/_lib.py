@@ -54,6 +54,7 @@ PROTOTYPES = {
     "batched_rollout": (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs)]),
     "batched_step_host": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
     "batched_reset_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "soccer_set_policy": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "soccer_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "soccer_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "soccer_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),

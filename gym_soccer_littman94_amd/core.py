@@ -164,6 +164,15 @@ class SoccerBatch:
                         _ptr(return_sum), _ptr(episode_count))
         self._check(self.lib.batched_rollout(self.h, C.byref(a)))
 
+    def set_policy(self, player, policy):
+        """Fixed policy for 'player_a' / 'player_b' (dict or sequence: observation index -> action), or None."""
+        idx = {"player_a": 0, "player_b": 1, 0: 0, 1: 1}[player]
+        if policy is None:
+            self._check(self.lib.soccer_set_policy(self.h, idx, None, 0)); return
+        arr = np.array([policy[s] for s in range(self.nS)], dtype=np.int8) if isinstance(policy, dict) \
+            else np.ascontiguousarray(policy, dtype=np.int8)
+        self._check(self.lib.soccer_set_policy(self.h, idx, arr.ctypes.data, int(arr.size)))
+
     # -- host-array variants (numpy in, numpy out; one staged copy each way) -------------------
     def reset_host(self, mask=None, u_reset=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
@@ -175,14 +184,16 @@ class SoccerBatch:
 
     def step_host(self, act_a, act_b, u_step=None, u_reset=None):
         n = self.n
-        a = np.ascontiguousarray(act_a, np.int8); b = np.ascontiguousarray(act_b, np.int8)
-        assert a.shape == (n,) and b.shape == (n,), "actions must have one entry per environment"
+        a = None if act_a is None else np.ascontiguousarray(act_a, np.int8)
+        b = None if act_b is None else np.ascontiguousarray(act_b, np.int8)
+        assert (a is None or a.shape == (n,)) and (b is None or b.shape == (n,)), \
+            "actions must have one entry per environment"
         us = None if u_step is None else np.ascontiguousarray(u_step, np.float64)
         ur = None if u_reset is None else np.ascontiguousarray(u_reset, np.float64)
         out = {"obs": np.empty(n, np.uint16), "reward": np.empty(n, np.int8),
                "terminated": np.empty(n, np.uint8), "truncated": np.empty(n, np.uint8),
                "prob_code": np.empty(n, np.uint8), "final_obs": np.empty(n, np.uint16)}
-        args = StepArgs(a.ctypes.data, b.ctypes.data, None if us is None else us.ctypes.data,
+        args = StepArgs(None if a is None else a.ctypes.data, None if b is None else b.ctypes.data, None if us is None else us.ctypes.data,
                         None if ur is None else ur.ctypes.data, out["obs"].ctypes.data,
                         out["reward"].ctypes.data, out["terminated"].ctypes.data,
                         out["truncated"].ctypes.data, out["prob_code"].ctypes.data,

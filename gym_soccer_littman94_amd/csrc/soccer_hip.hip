@@ -35,6 +35,7 @@ struct soccer_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // device buffers owned by the handle
     uint16_t* d_lut = nullptr; uint32_t* d_nc = nullptr; uint32_t* d_isd = nullptr;
+    int8_t* d_policy[2] = {nullptr, nullptr};
     unsigned long long* d_tick = nullptr;   // two slots, 128 B apart
     unsigned long long* d_hist = nullptr;
     unsigned int* d_misuse = nullptr;
@@ -91,7 +92,7 @@ static void free_handle(soccer_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -312,7 +313,8 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
 
 extern "C" int batched_step_ex(soccer_handle* h, const soccer_step_args* a) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
-    if (!a || !a->act_a || !a->act_b) return fail(h, SOCCER_E_INVALID, "batched_step: act_a and act_b are required");
+    if (!a || (!a->act_a && !h->P.policy_a) || (!a->act_b && !h->P.policy_b))
+        return fail(h, SOCCER_E_INVALID, "batched_step: an action stream is required for every player without a fixed policy");
     if (!aligned(a->u_step, 8) || !aligned(a->u_reset, 8) || !aligned(a->obs, 2) || !aligned(a->final_obs, 2))
         return fail(h, SOCCER_E_INVALID, "batched_step: u_* must be 8-byte and obs/final_obs 2-byte aligned");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -320,7 +322,7 @@ extern "C" int batched_step_ex(soccer_handle* h, const soccer_step_args* a) {
     const bool vec = h->E != 1 && aligned(a->act_a, 4) && aligned(a->act_b, 4) && aligned(a->reward, 4) &&
                      aligned(a->terminated, 4) && aligned(a->truncated, 4) && aligned(a->prob_code, 4) &&
                      aligned(a->obs, 8) && aligned(a->final_obs, 8);
-    const bool explicit_u = a->u_step || a->u_reset;
+    const bool explicit_u = a->u_step || a->u_reset || h->P.policy_a || h->P.policy_b;   // generic kernel
     KernelParams P = h->P;
     bind_tick(h, P, 1);
     StepIO io{a->act_a, a->act_b, a->u_step, a->u_reset, a->obs, a->reward, a->terminated, a->truncated,
@@ -361,8 +363,8 @@ static void launch_rollout(soccer_handle* h, const KernelParams& P, const Rollou
 extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (!a || a->n_steps < 1) return fail(h, SOCCER_E_INVALID, "batched_rollout: n_steps must be >= 1");
-    if (!a->sample_actions && (!a->act_a || !a->act_b))
-        return fail(h, SOCCER_E_INVALID, "batched_rollout: act_a/act_b required unless sample_actions");
+    if (!a->sample_actions && ((!a->act_a && !h->P.policy_a) || (!a->act_b && !h->P.policy_b)))
+        return fail(h, SOCCER_E_INVALID, "batched_rollout: an action stream is required for every player without a fixed policy (or sample_actions)");
     if (!a->sample_actions && a->act_stride < (int64_t)h->P.n)
         return fail(h, SOCCER_E_INVALID, "batched_rollout: act_stride must be >= n_lanes");
     const bool any_out = a->obs || a->reward || a->terminated || a->truncated;
@@ -498,18 +500,21 @@ int ensure_stage(soccer_handle* h, const StageLayout& L) {
 extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_step_host during graph capture");
-    if (!a || !a->act_a || !a->act_b) return fail(h, SOCCER_E_INVALID, "batched_step: act_a and act_b are required");
+    if (!a || (!a->act_a && !h->P.policy_a) || (!a->act_b && !h->P.policy_b))
+        return fail(h, SOCCER_E_INVALID, "batched_step: an action stream is required for every player without a fixed policy");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t n = h->P.n;
     const StageLayout L = stage_layout(n);
     if (int rc = ensure_stage(h, L)) return rc;
     uint8_t* H = h->stage_host; uint8_t* D = h->stage_dev;
-    std::memcpy(H + L.act_a, a->act_a, n); std::memcpy(H + L.act_b, a->act_b, n);
+    if (a->act_a) std::memcpy(H + L.act_a, a->act_a, n);
+    if (a->act_b) std::memcpy(H + L.act_b, a->act_b, n);
     if (a->u_step) std::memcpy(H + L.u_step, a->u_step, 8 * n);
     if (a->u_reset) std::memcpy(H + L.u_reset, a->u_reset, 8 * n);
     HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
     soccer_step_args d{};
-    d.act_a = reinterpret_cast<const int8_t*>(D + L.act_a); d.act_b = reinterpret_cast<const int8_t*>(D + L.act_b);
+    d.act_a = a->act_a ? reinterpret_cast<const int8_t*>(D + L.act_a) : nullptr;
+    d.act_b = a->act_b ? reinterpret_cast<const int8_t*>(D + L.act_b) : nullptr;
     d.u_step = a->u_step ? reinterpret_cast<const double*>(D + L.u_step) : nullptr;
     d.u_reset = a->u_reset ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr;
     d.obs = reinterpret_cast<uint16_t*>(D + L.obs); d.final_obs = reinterpret_cast<uint16_t*>(D + L.final_obs);
@@ -545,6 +550,27 @@ extern "C" int batched_reset_host(soccer_handle* h, const uint8_t* mask, const d
     HIP_TRY(h, hipMemcpyAsync(H + L.obs, D + L.obs, 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (obs) std::memcpy(obs, H + L.obs, 2 * n);
+    return SOCCER_OK;
+}
+
+// single-agent mode: one side follows a fixed policy looked up by the current observation index
+// (reference :54-56, :187-188).  policy_host NULL clears it.
+extern "C" int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_host, int32_t n_states) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_set_policy during graph capture");
+    if (player != 0 && player != 1) return fail(h, SOCCER_E_INVALID, "player must be 0 (player_a) or 1 (player_b)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int8_t** slot = player == 0 ? &h->P.policy_a : &h->P.policy_b;
+    if (!policy_host) { *slot = nullptr; return SOCCER_OK; }
+    if (n_states != h->rules.nS) return fail(h, SOCCER_E_INVALID, "policy must have one action per observation index (%d)", h->rules.nS);
+    if ((player == 0 ? h->P.policy_b : h->P.policy_a) != nullptr)
+        return fail(h, SOCCER_E_INVALID, "Both players cannot have a policy. At least one must be None.");   // :38
+    for (int i = 0; i < n_states; ++i)
+        if (policy_host[i] < 0 || policy_host[i] > 4) return fail(h, SOCCER_E_INVALID, "policy[%d] = %d is not an action", i, (int)policy_host[i]);
+    if (!h->d_policy[player]) HIP_TRY(h, hipMalloc(&h->d_policy[player], (size_t)h->rules.nS));
+    HIP_TRY(h, hipMemcpy(h->d_policy[player], policy_host, (size_t)n_states, hipMemcpyHostToDevice));
+    *slot = h->d_policy[player];
     return SOCCER_OK;
 }
 

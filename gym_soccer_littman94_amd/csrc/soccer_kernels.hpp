@@ -36,6 +36,8 @@ struct KernelParams {
     const uint16_t* lut;                  // [lut_len] observation index per state tuple
     const uint32_t* next_cell;            // [2][H*W][5]: (has_ball, cell, move) -> (row<<8|col)<<16 | (row*W+col) reached
     const uint32_t* isd;                  // [kIsdWords]
+    // single-agent mode: the fixed side's action per observation index (int8[nS]), or nullptr
+    const int8_t* policy_a; const int8_t* policy_b;
     // randomness
     const unsigned long long* tick_in;    // device tick slot read by this launch
     unsigned long long* tick_out;         // slot written (tick_in + ticks consumed)
@@ -540,7 +542,9 @@ __device__ __forceinline__ void store4h(uint16_t* base, unsigned long long i, in
 // VEC:    the launch covers a multiple of 4 lanes starting at a multiple of 4, all streams dword-aligned
 //         (the host sends a ragged tail / misaligned buffers to the VEC = false instantiation);
 // SHARED: (lane_offset + first) % 4 == 0, so a thread's 4 lanes are exactly one Philox block;
-// EXPLICIT_U: caller-supplied uniforms (u_step / u_reset) may replace the Philox draw.
+// EXPLICIT_U ("generic"): caller-supplied uniforms (u_step / u_reset) may replace the Philox draw, and
+//         a fixed-policy side (single-agent mode, reference :187-188) takes its action from
+//         policy[observation of the current tuple] instead of the action stream.
 // The hot instantiation <SLIP=false, EXPLICIT_U=false, VEC=true, SHARED=true> carries none of the
 // fallback code.
 template <bool SLIP, bool EXPLICIT_U, bool VEC, bool SHARED, int UNROLL = 1, int BLOCK = kBlock>
@@ -559,7 +563,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
         uint32_t ra = load4<VEC>(sp, i0, cnt), ca = load4<VEC>(sp + P.state_stride, i0, cnt);
         uint32_t rb = load4<VEC>(sp + 2 * P.state_stride, i0, cnt), cb = load4<VEC>(sp + 3 * P.state_stride, i0, cnt);
         uint32_t ps = load4<VEC>(sp + 4 * P.state_stride, i0, cnt), tt = load4<VEC>(sp + 5 * P.state_stride, i0, cnt);
-        uint32_t aa = load4<VEC>(IO.act_a, i0, cnt), ab = load4<VEC>(IO.act_b, i0, cnt);
+        uint32_t aa = 0u, ab = 0u;
+        if (!EXPLICIT_U || !P.policy_a) aa = load4<VEC>(IO.act_a, i0, cnt);
+        if (!EXPLICIT_U || !P.policy_b) ab = load4<VEC>(IO.act_b, i0, cnt);
         // randomness does not depend on the loads above: it is computed while they are in flight
         const bool need_philox = !EXPLICIT_U || (IO.u_step == nullptr) || (P.autoreset && IO.u_reset == nullptr);
         Philox4 blk{{0u, 0u, 0u, 0u}};
@@ -583,8 +589,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
             Lane L;
             L.A = make_pos(ra & 0xffu, ca & 0xffu, P.W); L.B = make_pos(rb & 0xffu, cb & 0xffu, P.W);
             L.p = ps & 1u; L.need = (ps >> 1) & 1u; L.t = tt & 0xffu;
+            uint32_t a_now = aa & 0xffu, b_now = ab & 0xffu;
+            if (EXPLICIT_U && (P.policy_a || P.policy_b)) {         // the fixed side acts on the current observation
+                const uint32_t s_now = obs_of(T, P, L.A, L.B, L.p);
+                if (P.policy_a) a_now = (uint32_t)(uint8_t)P.policy_a[s_now];
+                if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
+            }
             StepResult R;
-            mis |= lane_step<SLIP>(T, P, L, aa & 0xffu, ab & 0xffu, d, R);
+            mis |= lane_step<SLIP>(T, P, L, a_now, b_now, d, R);
             ra >>= 8; ca >>= 8; rb >>= 8; cb >>= 8; ps >>= 8; tt >>= 8; aa >>= 8; ab >>= 8;
             nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
             nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
@@ -664,13 +676,20 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
 #pragma unroll
     for (int j = 0; j < E; ++j) { ret[j] = 0; eps[j] = 0; }
     PackB<E> aa, ab; aa.clear(); ab.clear();
-    if (!IO.sample_actions) { aa.load(IO.act_a, i0); ab.load(IO.act_b, i0); }
+    if (!IO.sample_actions) {
+        if (IO.act_a) aa.load(IO.act_a, i0);
+        if (IO.act_b) ab.load(IO.act_b, i0);
+    }
+    const bool fixed = P.policy_a != nullptr || P.policy_b != nullptr;      // single-agent mode
+    uint32_t s_now[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) s_now[j] = fixed ? obs_of(T, P, S.L[j].A, S.L[j].B, S.L[j].p) : 0u;
     for (int s = 0; s < IO.n_steps; ++s) {
         const unsigned long long tick = tick0 + (unsigned long long)s;
         PackB<E> naa = aa, nab = ab;
         if (!IO.sample_actions && s + 1 < IO.n_steps) {                 // prefetch the next step's actions
-            naa.load(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
-            nab.load(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
+            if (IO.act_a) naa.load(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
+            if (IO.act_b) nab.load(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
         }
         uint32_t words[E], awords[E];
         lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
@@ -685,8 +704,13 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
                 a = ((awords[j] & 0xffffu) * 5u) >> 16;
                 b = ((awords[j] >> 16) * 5u) >> 16;
             }
+            if (fixed) {
+                if (P.policy_a) a = (uint32_t)(uint8_t)P.policy_a[s_now[j]];
+                if (P.policy_b) b = (uint32_t)(uint8_t)P.policy_b[s_now[j]];
+            }
             StepResult R;
             any_misuse |= lane_step<SLIP>(T, P, S.L[j], a, b, d, R);
+            s_now[j] = R.obs;
             o_obs.put(j, R.obs); o_rew.put(j, (uint32_t)R.reward & 0xffu); o_term.put(j, R.term); o_trunc.put(j, R.trunc);
             ret[j] += R.reward; eps[j] += (int32_t)R.finished;
             hist.add(R.finished, R.reward);

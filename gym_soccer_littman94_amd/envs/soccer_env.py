@@ -39,6 +39,11 @@ class SoccerSimultaneousEnv:
         assert width >= 5, "Width must be at least 5 columns."
         assert height >= 4, "Height must be at least 4 rows."
         self._batch = SoccerBatch(1, width, height, slip_prob, seed=seed, autoreset=False, device=device)
+        # single-agent mode: the fixed side's policy lives on the device and is looked up by the kernel
+        if player_a_policy is not None:
+            self._batch.set_policy('player_a', player_a_policy)
+        if player_b_policy is not None:
+            self._batch.set_policy('player_b', player_b_policy)
         self.width = width + 2                      # +2 goal columns (:48)
         self.height = height
         self.slip_prob = slip_prob
@@ -130,13 +135,12 @@ class SoccerSimultaneousEnv:
             assert len(action) == 1, "Action must be a dictionary of length 1 for single agent case"
             assert 'player_a' in action or 'player_b' in action, "Action must contain either 'player_a' or 'player_b'"
         self._push_state()
-        # the fixed side's action is looked up by the current observation (:187-188)
-        s = self._state_to_observation(tuple(self.state))
-        aa = int(action['player_a']) if self.player_a_policy is None else int(self.player_a_policy[s])
-        ab = int(action['player_b']) if self.player_b_policy is None else int(self.player_b_policy[s])
-        assert 0 <= aa < self.nA and 0 <= ab < self.nA, "actions must be in 0..4"
+        # the fixed side's action is looked up by the kernel from the current observation (:187-188)
+        aa = None if self.player_a_policy is not None else [int(action['player_a'])]
+        ab = None if self.player_b_policy is not None else [int(action['player_b'])]
+        assert all(x is None or 0 <= x[0] < self.nA for x in (aa, ab)), "actions must be in 0..4"
         u = self.np_random.random()                  # one uniform per step (:395)
-        out = self._batch.step_host([aa], [ab], u_step=[u])
+        out = self._batch.step_host(aa, ab, u_step=[u])
         self._pull_state()
         prob = self._batch.prob_table[int(out["prob_code"][0])]
         reward = float(out["reward"][0])

@@ -29,8 +29,10 @@ class VectorSoccerEnv:
 
     def __init__(self, num_envs, width=5, height=4, slip_prob=0.0, seed=0, autoreset=True,
                  device=0, lane_offset=0, max_episode_steps=100, io="numpy", strict=True,
-                 envs_per_thread=0):
+                 envs_per_thread=0, player_a_policy=None, player_b_policy=None):
         assert io in ("numpy", "device"), "io must be 'numpy' or 'device'"
+        assert not (player_a_policy is not None and player_b_policy is not None), \
+            "Both players cannot have a policy. At least one must be None."
         self.num_envs = int(num_envs)
         self.io = io
         self.strict = strict
@@ -47,14 +49,22 @@ class VectorSoccerEnv:
         self.width, self.height, self.slip_prob = width + 2, height, slip_prob
         self.nS, self.nA = b.nS, b.nA
         self.autoreset = bool(autoreset)
-        self.return_agent = list(AGENTS)
-        self.multiagent = True
-        self.single_observation_space = spaces.Dict({a: spaces.Discrete(self.nS) for a in AGENTS})
-        self.single_action_space = spaces.Dict({a: spaces.Discrete(self.nA) for a in AGENTS})
+        # single-agent mode (reference :54-56): the side with a policy is played by the kernel
+        self.player_a_policy, self.player_b_policy = player_a_policy, player_b_policy
+        self.multiagent = player_a_policy is None and player_b_policy is None
+        self.return_agent = list(AGENTS) if self.multiagent else \
+            ['player_a'] if player_a_policy is None else ['player_b']
+        if player_a_policy is not None:
+            b.set_policy('player_a', player_a_policy)
+        if player_b_policy is not None:
+            b.set_policy('player_b', player_b_policy)
+        ags = self.return_agent
+        self.single_observation_space = spaces.Dict({a: spaces.Discrete(self.nS) for a in ags})
+        self.single_action_space = spaces.Dict({a: spaces.Discrete(self.nA) for a in ags})
         self.observation_space = spaces.Dict(
-            {a: spaces.MultiDiscrete(np.full(self.num_envs, self.nS)) for a in AGENTS})
+            {a: spaces.MultiDiscrete(np.full(self.num_envs, self.nS)) for a in ags})
         self.action_space = spaces.Dict(
-            {a: spaces.MultiDiscrete(np.full(self.num_envs, self.nA)) for a in AGENTS})
+            {a: spaces.MultiDiscrete(np.full(self.num_envs, self.nA)) for a in ags})
         self._needs_reset = True
         if io == "device":
             t, n, d = self._torch, self.num_envs, self._dev
@@ -75,20 +85,31 @@ class VectorSoccerEnv:
         p = np.round(1.0 / b.n_isd, 2)
         if self.io == "numpy":
             obs = b.reset_host(mask=mask)
-            infos = {a: {"p": np.full(self.num_envs, p)} for a in AGENTS}
+            infos = {a: {"p": np.full(self.num_envs, p)} for a in self.return_agent}
             self._needs_reset = False
-            return {a: obs for a in AGENTS}, infos
+            return {a: obs for a in self.return_agent}, infos
         m = None if mask is None else mask.to(self._torch.uint8)
         b.reset(mask=m, obs=self._obs)
         self._needs_reset = False
-        infos = {a: {"p": self._torch.full((self.num_envs,), float(p), device=self._dev)} for a in AGENTS}
-        return {a: self._obs for a in AGENTS}, infos
+        infos = {a: {"p": self._torch.full((self.num_envs,), float(p), device=self._dev)} for a in self.return_agent}
+        return {a: self._obs for a in self.return_agent}, infos
 
     def _check_actions(self, action):
         assert isinstance(action, dict), "Action must be a dictionary"
-        assert len(action) == 2, "Action must be a dictionary of length 2 for multiagent case"
-        assert 'player_a' in action and 'player_b' in action, "Action must contain both 'player_a' and 'player_b'"
-        return action['player_a'], action['player_b']
+        if self.multiagent:
+            assert len(action) == 2, "Action must be a dictionary of length 2 for multiagent case"
+            assert 'player_a' in action and 'player_b' in action, "Action must contain both 'player_a' and 'player_b'"
+        else:
+            assert len(action) == 1, "Action must be a dictionary of length 1 for single agent case"
+            assert self.return_agent[0] in action, "Action must contain the learner's key only"
+        return action.get('player_a'), action.get('player_b')
+
+    def _rewards(self, r):
+        """player A's reward array -> dict per returned agent; B's is the negation (:400-402, :243-244)."""
+        out = {}
+        if 'player_a' in self.return_agent: out['player_a'] = r
+        if 'player_b' in self.return_agent: out['player_b'] = -r
+        return out
 
     def step(self, action):
         assert not self._needs_reset, "Please reset the environment before taking a step"
@@ -96,34 +117,41 @@ class VectorSoccerEnv:
         b = self._batch
         n = self.num_envs
         if self.io == "numpy":
-            a = np.asarray(a); bb = np.asarray(bb)
-            assert a.shape == (n,) and bb.shape == (n,), "one action per environment and agent"
-            assert ((a >= 0) & (a < self.nA)).all() and ((bb >= 0) & (bb < self.nA)).all(), "actions must be in 0..4"
-            out = b.step_host(a.astype(np.int8, copy=False), bb.astype(np.int8, copy=False))
+            acts = []
+            for x in (a, bb):
+                if x is None:
+                    acts.append(None); continue
+                x = np.asarray(x)
+                assert x.shape == (n,), "one action per environment and agent"
+                assert ((x >= 0) & (x < self.nA)).all(), "actions must be in 0..4"
+                acts.append(x.astype(np.int8, copy=False))
+            out = b.step_host(acts[0], acts[1])
             if self.strict:
                 self._raise_on_misuse()
             r = out["reward"].astype(np.float32)
             term = out["terminated"].view(np.bool_); trunc = out["truncated"].view(np.bool_)
             p = np.round(b.prob_table[out["prob_code"]], 2)
             fin_mask = term | trunc
-            infos = {ag: {"p": p} for ag in AGENTS}
-            infos["final_observation"] = {ag: out["final_obs"] for ag in AGENTS}
+            ags = self.return_agent
+            infos = {ag: {"p": p} for ag in ags}
+            infos["final_observation"] = {ag: out["final_obs"] for ag in ags}
             infos["_final_observation"] = fin_mask
-            return ({ag: out["obs"] for ag in AGENTS}, {'player_a': r, 'player_b': -r},
-                    {ag: term for ag in AGENTS}, {ag: trunc for ag in AGENTS}, infos)
+            return ({ag: out["obs"] for ag in ags}, self._rewards(r),
+                    {ag: term for ag in ags}, {ag: trunc for ag in ags}, infos)
         t = self._torch
-        assert a.dtype == t.int8 and bb.dtype == t.int8 and a.is_cuda and bb.is_cuda, \
-            "device io expects torch.int8 CUDA tensors (values 0..4; not re-validated on the hot path)"
-        assert a.shape == (n,) and bb.shape == (n,) and a.is_contiguous() and bb.is_contiguous()
+        for x in (a, bb):
+            assert x is None or (x.dtype == t.int8 and x.is_cuda and x.shape == (n,) and x.is_contiguous()), \
+                "device io expects contiguous torch.int8 CUDA tensors (values 0..4; not re-validated on the hot path)"
         b.step(a, bb, obs=self._obs, reward=self._rew, terminated=self._term, truncated=self._trunc,
                prob_code=self._code, final_obs=self._fin)
         r = self._rew.to(t.float32)
         term = self._term.bool(); trunc = self._trunc.bool()
-        infos = {ag: {"p": self._prob[self._code.long()]} for ag in AGENTS}
-        infos["final_observation"] = {ag: self._fin for ag in AGENTS}
+        ags = self.return_agent
+        infos = {ag: {"p": self._prob[self._code.long()]} for ag in ags}
+        infos["final_observation"] = {ag: self._fin for ag in ags}
         infos["_final_observation"] = term | trunc
-        return ({ag: self._obs for ag in AGENTS}, {'player_a': r, 'player_b': -r},
-                {ag: term for ag in AGENTS}, {ag: trunc for ag in AGENTS}, infos)
+        return ({ag: self._obs for ag in ags}, self._rewards(r),
+                {ag: term for ag in ags}, {ag: trunc for ag in ags}, infos)
 
     def _raise_on_misuse(self):
         hist, misuse = self._batch.stats()

@@ -93,7 +93,8 @@ typedef struct soccer_config {
     void*    stream;        /* hipStream_t to enqueue on, or NULL: the handle creates its own */
 } soccer_config;
 
-/* batched_step_ex arguments.  Required: act_a, act_b.  Every output may be NULL (skipped). */
+/* batched_step_ex arguments.  Required: act_a, act_b (each unless that player has a fixed policy).
+ * Every output may be NULL (skipped). */
 typedef struct soccer_step_args {
     const int8_t*  act_a;       /* [n] action of player A, 0..4 */
     const int8_t*  act_b;       /* [n] action of player B, 0..4 */
@@ -159,6 +160,13 @@ int batched_rollout(soccer_handle* h, const soccer_rollout_args* args);
  * arrays.  last_return must be NULL. */
 int batched_step_host(soccer_handle* h, const soccer_step_args* host_args);
 int batched_reset_host(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs);
+
+/* Single-agent mode (reference :54-56, :187-188, :266-279): `player` (0 = player_a, 1 = player_b) follows
+ * a fixed policy — HOST int8[n_states], action per observation index — looked up with the observation
+ * of the CURRENT tuple before every step; that player's action stream may then be NULL.  Only one
+ * side may have a policy (:38).  policy NULL clears it.  Rewards stay player A's (+1 A scores); a
+ * learner-B host negates them as the reference's table does (:243-244). */
+int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_host, int32_t n_states);
 
 /* ---- state injection / readback (`env.state = tuple`, tests/test_deterministic...py:43) -- */
 /* HOST pointers of n_lanes elements; any pointer may be NULL (field left unchanged / not read).

@@ -286,6 +286,37 @@ def test_vector_env_numpy_matches_oracle_and_gym_autoreset_convention():
     v.close()
 
 
+@pytest.mark.parametrize("learner", ["player_a", "player_b"])
+def test_vector_env_single_agent_mode(learner):
+    n, T = 1024, 80
+    rng = np.random.default_rng(31)
+    policy = {s: int(a) for s, a in enumerate(rng.integers(0, 5, size=761))}
+    parr = np.array([policy[s] for s in range(761)], np.int8)
+    kw = {"player_b_policy": policy} if learner == "player_a" else {"player_a_policy": policy}
+    v = VectorSoccerEnv(n, slip_prob=0.2, seed=2, **kw)
+    o = Oracle(5, 4, 0.2, n=n, seed=2, autoreset=True)
+    assert not v.multiagent and v.return_agent == [learner] and list(v.action_space) == [learner]
+    obs, info = v.reset(seed=2)
+    cur = o.reset()
+    assert set(obs) == set(info) == {learner}
+    np.testing.assert_array_equal(obs[learner], cur)
+    for k in range(T):
+        a = rng.integers(0, 5, size=n)
+        ob, rw, te, tr, inf = v.step({learner: a})
+        c = o.step(a, parr[cur]) if learner == "player_a" else o.step(parr[cur], a)
+        assert set(ob) == set(rw) == set(te) == set(tr) == {learner}
+        np.testing.assert_array_equal(ob[learner], c["obs"])
+        sign = 1.0 if learner == "player_a" else -1.0
+        np.testing.assert_array_equal(rw[learner], sign * c["reward"].astype(np.float32))
+        np.testing.assert_array_equal(te[learner], c["terminated"].astype(bool))
+        cur = c["obs"]
+    with pytest.raises(AssertionError):
+        v.step({'player_a': a, 'player_b': a})
+    with pytest.raises(AssertionError, match="Both players"):
+        VectorSoccerEnv(8, player_a_policy=policy, player_b_policy=policy)
+    v.close()
+
+
 def test_vector_env_without_autoreset_is_strict_like_the_reference():
     n = 512
     rng = np.random.default_rng(2)

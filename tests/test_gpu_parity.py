@@ -200,6 +200,60 @@ def test_config2_autoreset_every_lane_every_step_vs_oracle(slip, width, height, 
     b.close()
 
 
+@pytest.mark.parametrize("learner", ["player_a", "player_b"])
+def test_single_agent_tables_every_row(learner):
+    """Fixed-opponent mode against the REFERENCE's single-agent transition table (all ~43 000 rows):
+    one lane per table row, put in the row's state, fed a uniform from the middle of the row's
+    probability interval; the kernel (which looks the opponent's action up from the policy by the
+    current observation) must land on exactly that row's next state / reward / done."""
+    g = np.load(os.path.join(GOLDEN, "single_5x4_s0p2_%s.npz" % learner))
+    rows, prob = g["rows"], g["prob"]      # xa,ya,xb,yb,p, a, k, nxa,nya,nxb,nyb,np, reward, done
+    n = len(rows)
+    starts = np.flatnonzero(rows[:, 6] == 0)
+    cum = np.zeros(n); lo = np.zeros(n)
+    for s_, e_ in zip(starts, np.append(starts[1:], n)):
+        c = np.cumsum(prob[s_:e_]); cum[s_:e_] = c; lo[s_:e_] = np.concatenate([[0.0], c[:-1]])
+    u = (lo + np.minimum(cum, 1.0)) / 2
+    assert (u > lo).all() and (u < cum).all()
+    b = SoccerBatch(n, 5, 4, 0.2)
+    b.set_policy("player_b" if learner == "player_a" else "player_a", g["policy"])
+    b.set_state(rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3], rows[:, 4], t=0, needs_reset=0)
+    acts = rows[:, 5].astype(np.int8)
+    out = b.step_host(acts if learner == "player_a" else None, acts if learner == "player_b" else None, u_step=u)
+    s = b.get_state()
+    got = np.stack([s["row_a"], s["col_a"], s["row_b"], s["col_b"], s["poss"]], 1)
+    np.testing.assert_array_equal(got, rows[:, 7:12])
+    sign = 1 if learner == "player_a" else -1          # the reference's learner-B table stores -r (:243-244)
+    np.testing.assert_array_equal(sign * out["reward"], rows[:, 12])
+    np.testing.assert_array_equal(out["terminated"], rows[:, 13])
+    np.testing.assert_array_equal(b.prob_table[out["prob_code"]], prob)
+    with pytest.raises(AssertionError, match="Both players"):
+        b.set_policy(learner, g["policy"])
+    b.close()
+
+
+def test_single_agent_rollout_and_step_agree_with_oracle_policy_gather():
+    n, T = 8192, 90
+    rng = np.random.default_rng(12)
+    policy = rng.integers(0, 5, size=761).astype(np.int8)
+    acts = rng.integers(0, 5, size=(T, n), dtype=np.int8)
+    b = SoccerBatch(n, 5, 4, 0.2, seed=6, autoreset=True); b.set_policy("player_b", policy)
+    b2 = SoccerBatch(n, 5, 4, 0.2, seed=6, autoreset=True); b2.set_policy("player_b", policy)
+    o = Oracle(5, 4, 0.2, n=n, seed=6, autoreset=True)
+    cur = o.reset(); b.reset(); b2.reset()
+    A = b.alloc((T, n), np.int8).upload(acts); obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8)
+    b.rollout(T, A, None, act_stride=n, obs=obs, reward=rew, out_stride=n)
+    O, R = obs.download(), rew.download()
+    for k in range(T):
+        c = o.step(acts[k], policy[cur])                 # the oracle side does the gather on the host
+        g2 = b2.step_host(acts[k], None)
+        np.testing.assert_array_equal(O[k], c["obs"]); np.testing.assert_array_equal(R[k], c["reward"])
+        np.testing.assert_array_equal(g2["obs"], c["obs"]); np.testing.assert_array_equal(g2["reward"], c["reward"])
+        cur = c["obs"]
+    assert_state_equal(b, o); assert_state_equal(b2, o)
+    b.close(); b2.close()
+
+
 def test_no_autoreset_freezes_finished_lanes_and_flags_misuse():
     n = 4096
     rng = np.random.default_rng(7)
