@@ -141,6 +141,16 @@ class SoccerBatch:
         self._check(self.lib.soccer_get_tables(self.h, lut.ctypes.data, goal_value.ctypes.data, isd.ctypes.data))
         return lut, goal_value, isd
 
+    def transitions(self):
+        """The full transition relation (the reference's P_readable), enumerated on the device.
+        Returns count[T,25] (-1: unreachable tuple), prob[T,25,36], next_flat[T,25,36], reward, done."""
+        T = self.lut_len
+        count = np.zeros((T, 25), np.int32); prob = np.zeros((T, 25, 36), np.float64)
+        nxt = np.zeros((T, 25, 36), np.int32); rew = np.zeros((T, 25, 36), np.int8); done = np.zeros((T, 25, 36), np.uint8)
+        self._check(self.lib.soccer_enumerate_transitions(self.h, count.ctypes.data, prob.ctypes.data,
+                                                          nxt.ctypes.data, rew.ctypes.data, done.ctypes.data))
+        return count, prob, nxt, rew, done
+
     # -- hot path -------------------------------------------------------------------------------
     def reset(self, mask=None, u_reset=None, obs=None):
         self._check(self.lib.batched_reset(self.h, _ptr(mask), _ptr(u_reset), _ptr(obs)))

@@ -553,6 +553,36 @@ extern "C" int batched_reset_host(soccer_handle* h, const uint8_t* mask, const d
     return SOCCER_OK;
 }
 
+// the reference's P_readable, computed on the device by the rule functions of the step kernels
+extern "C" int soccer_enumerate_transitions(soccer_handle* h, int32_t* count, double* prob, int32_t* next_flat,
+                                            int8_t* reward, uint8_t* done) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_enumerate_transitions during graph capture");
+    if (!count || !prob || !next_flat || !reward || !done) return fail(h, SOCCER_E_INVALID, "all five outputs are required");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t keys = h->rules.lut.size() * 25, ent = keys * kMaxOutcomes;
+    EnumIO io{};
+    io.n_tuples = static_cast<int32_t>(h->rules.lut.size()); io.H = h->rules.H;
+    void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t sizes[5] = {keys * sizeof(int32_t), ent * sizeof(double), ent * sizeof(int32_t), ent, ent};
+    int rc = SOCCER_OK;
+    for (int i = 0; i < 5 && rc == SOCCER_OK; ++i)
+        if (hipMalloc(&bufs[i], sizes[i]) != hipSuccess) rc = fail(h, SOCCER_E_NOMEM, "out of device memory for the transition table");
+    if (rc == SOCCER_OK) {
+        io.count = static_cast<int32_t*>(bufs[0]); io.prob = static_cast<double*>(bufs[1]);
+        io.next = static_cast<int32_t*>(bufs[2]); io.reward = static_cast<int8_t*>(bufs[3]); io.done = static_cast<uint8_t*>(bufs[4]);
+        const unsigned grid = static_cast<unsigned>((keys + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(enumerate_kernel, dim3(grid), dim3(kBlock), 0, h->stream, h->P, io);
+        void* dst[5] = {count, prob, next_flat, reward, done};
+        hipError_t e = hipGetLastError();
+        for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipMemcpyAsync(dst[i], bufs[i], sizes[i], hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, SOCCER_E_HIP, "transition table export failed: %s", hipGetErrorString(e));
+    }
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    return rc;
+}
+
 // single-agent mode: one side follows a fixed policy looked up by the current observation index
 // (reference :54-56, :187-188).  policy_host NULL clears it.
 extern "C" int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_host, int32_t n_states) {

@@ -750,4 +750,69 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const KernelParams P, c
     hist.flush(P);
 }
 
+// =================================================================================================
+// transition-table export: what the reference's constructor materialises as P_readable (:167-293)
+// =================================================================================================
+constexpr int kMaxOutcomes = 36;         // 9 slip combinations x up to 4 collision outcomes
+
+struct EnumIO {
+    int32_t* count;        // [n_tuples*25]   entries in the list, -1 for unreachable tuples (no key)
+    double* prob;          // [n_tuples*25*36]
+    int32_t* next;         // [n_tuples*25*36] flat tuple index of the next state
+    int8_t* reward;        // [n_tuples*25*36] player A's reward
+    uint8_t* done;         // [n_tuples*25*36]
+    int32_t n_tuples, H;
+};
+
+// One thread per (state tuple, joint action): the ordered outcome list exactly as the reference builds
+// it — combinations in order, zero weights dropped, collision outcomes in order, p = weight * outcome
+// probability — using the same rule functions (moved / classify / pick) as the step kernels.
+__global__ __launch_bounds__(kBlock) void enumerate_kernel(const KernelParams P, const EnumIO IO) {
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)IO.n_tuples * 25) return;
+    const int f = (int)(gid / 25), ja = (int)(gid % 25);
+    const uint32_t aa = (uint32_t)(ja / 5), ab = (uint32_t)(ja % 5);
+    int r = f;
+    const uint32_t p = r & 1; r >>= 1;
+    const uint32_t cb = r % P.W; r /= P.W;
+    const uint32_t rb = r % IO.H; r /= IO.H;
+    const uint32_t ca = r % P.W; const uint32_t ra = r / P.W;
+    const uint32_t lut = P.lut[f];
+    if (lut == 0xFFFFu) { IO.count[gid] = -1; return; }            // unreachable: the reference has no key (:179-180)
+    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
+    const uint32_t A = make_pos(ra, ca, P.W), B = make_pos(rb, cb, P.W);
+    const bool in_goal = lut == 0u;                                  // goal tuple (:300-301)
+    constexpr int VA[9] = {0, 0, 0, 1, 2, 1, 1, 2, 2};
+    constexpr int VB[9] = {0, 1, 2, 0, 0, 1, 2, 1, 2};
+    constexpr int CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+    const uint32_t Wm1 = (uint32_t)(P.W - 1);
+    int n = 0;
+    const long long base = gid * kMaxOutcomes;
+    for (int c = 0; c < 9; ++c) {
+        const double wgt = P.w[CLS[c]];
+        if (wgt == 0.0) continue;                                    // :226-227
+        if (in_goal) {                                               // absorbing self-loop, done, reward 0 (:235-236)
+            IO.prob[base + n] = wgt * 1.0; IO.next[base + n] = f; IO.reward[base + n] = 0; IO.done[base + n] = 1; ++n;
+            continue;
+        }
+        const uint32_t nA = moved(T, P, A, p ^ 1u, slip_move(aa, VA[c])), nB = moved(T, P, B, p, slip_move(ab, VB[c]));
+        const Resolved R = classify(A, B, nA, nB, aa, ab);
+        const int cnt = R.kind == K_COIN ? 2 : (R.kind == K_FOUR ? 4 : 1);
+        const double q = cnt == 1 ? 1.0 : (cnt == 2 ? 0.5 : 0.25);
+        for (int k = 0; k < cnt; ++k) {
+            const Outcome o = pick(A, B, p, R, (uint32_t)k);
+            const uint32_t ncc = col_of(o.p ? o.B : o.A);
+            const bool goal = (ncc == 0u) | (ncc == Wm1);
+            const int nf = (int)((((o.A >> 24) * (uint32_t)P.W + ((o.A >> 16) & 0xffu)) * (uint32_t)IO.H + (o.B >> 24)) * (uint32_t)P.W +
+                                 ((o.B >> 16) & 0xffu)) * 2 + (int)o.p;
+            IO.prob[base + n] = wgt * q;                             // :241
+            IO.next[base + n] = nf;
+            IO.reward[base + n] = goal ? (ncc == Wm1 ? 1 : -1) : 0;  // :237-240
+            IO.done[base + n] = goal ? 1 : 0;
+            ++n;
+        }
+    }
+    IO.count[gid] = n;
+}
+
 }  // namespace soccer

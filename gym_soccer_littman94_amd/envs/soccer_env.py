@@ -88,6 +88,69 @@ class SoccerSimultaneousEnv:
         self.timestep = 0
         self.lastaction = None
 
+    # ---- the reference's tables (P, P_readable, Pmat, Rmat; :167-293), built on first use ------------
+    # The transition relation is enumerated ON THE DEVICE by the rule functions of the step kernels
+    # (soccer_enumerate_transitions) in ~ms instead of the reference's 1 s (5x4) / 120 s (11x7) Python
+    # loops; this method only arranges it into the reference's dict / tensor shapes, quirks included
+    # (P[0] ends as the last goal tuple's lists, Pmat[0, 0] accumulates one unit per goal tuple).
+    def _build_tables(self):
+        count, prob, nxt, rew, done = self._batch.transitions()
+        lut = self._batch.tables()[0]
+        H, W = self.height, self.width
+        idx = np.arange(lut.size)
+        pp = idx & 1; r = idx >> 1
+        yb = r % W; r //= W; xb = r % H; r //= H; ya = r % W; xa = r // W
+        tuples = list(zip(xa.tolist(), ya.tolist(), xb.tolist(), yb.tolist(), pp.tolist()))
+        obs_of = np.where(lut == 0xFFFF, 0, lut).astype(np.int64)
+        flip = (not self.multiagent) and self.return_agent == ['player_b']      # :243-244
+        P, P_readable = {}, {}
+        nS, nA = self.nS, self.nA
+        if self.multiagent:
+            Pmat = np.zeros([nS, nS, nA, nA]); Rmat = np.zeros([nS, nA, nA])
+        else:
+            Pmat = np.zeros([nS, nS, nA]); Rmat = np.zeros([nS, nA])
+        AS = self.ACTION_STRING
+        for f in np.flatnonzero(count[:, 0] >= 0).tolist():
+            st = tuples[f]; s_ = int(obs_of[f])
+            P[s_] = {}; P_readable[st] = {}
+            aaa = range(nA) if self.player_a_policy is None else [int(self.player_a_policy[s_])]
+            aab = range(nA) if self.player_b_policy is None else [int(self.player_b_policy[s_])]
+            for aa in aaa:
+                for ab in aab:
+                    ja = aa * 5 + ab
+                    n = int(count[f, ja])
+                    ps = prob[f, ja, :n].tolist(); ns = nxt[f, ja, :n].tolist()
+                    rs = rew[f, ja, :n].tolist(); ds = done[f, ja, :n].tolist()
+                    trs, trs_r = [], []
+                    for k in range(n):
+                        rr = float(rs[k])
+                        if flip:
+                            rr = -1 * rr
+                        trs.append((ps[k], int(obs_of[ns[k]]), rr, bool(ds[k])))
+                        trs_r.append((ps[k], tuples[ns[k]], rr, bool(ds[k])))
+                    if self.multiagent:
+                        P[s_][(aa, ab)] = trs; P_readable[st][(AS[aa], AS[ab])] = trs_r
+                        Rmat[s_][aa][ab] = 0
+                        for pr, nso, rr, _d in trs:
+                            Pmat[s_][nso][aa][ab] += pr; Rmat[s_][aa][ab] += pr * rr
+                    else:
+                        a = aa if self.player_a_policy is None else ab
+                        P[s_][a] = trs; P_readable[st][AS[a]] = trs_r
+                        Rmat[s_][a] = 0
+                        for pr, nso, rr, _d in trs:
+                            Pmat[s_][nso][a] += pr; Rmat[s_][a] += pr * rr
+        self._tables = (P, P_readable, Pmat, Rmat)
+
+    def _table(self, i):
+        if getattr(self, "_tables", None) is None:
+            self._build_tables()
+        return self._tables[i]
+
+    P = property(lambda self: self._table(0))
+    P_readable = property(lambda self: self._table(1))
+    Pmat = property(lambda self: self._table(2))
+    Rmat = property(lambda self: self._table(3))
+
     def _state_to_observation(self, state):
         state = self.TERMINAL_STATE if state in self.goal_states else state
         return self.state_space[state]

@@ -185,6 +185,14 @@ int soccer_dims(const soccer_handle* h, int32_t* n_states, int32_t* lut_len,
  * 0xFFFF for unreachable tuples (:73-88); goal_value = +1/-1 for goal tuples (:94-102), else 0;
  * isd_states[n_isd][5] (:146-165). Any pointer may be NULL. */
 int soccer_get_tables(const soccer_handle* h, uint16_t* lut, int8_t* goal_value, int8_t* isd_states);
+/* The reference's transition relation P_readable (:167-293), computed on the device by the same rule
+ * functions the step kernels use.  HOST outputs, key = lut index * 25 + action_a * 5 + action_b:
+ *   count[key]           entries in the list (1..36), -1 for unreachable tuples (the reference has no key)
+ *   prob/next_flat/reward/done[key*36 + k]   k-th entry in the reference's list order: probability
+ *   (float64, weight * outcome probability, :241), lut index of the next tuple, player A's reward,
+ *   done (:235-240). */
+int soccer_enumerate_transitions(soccer_handle* h, int32_t* count, double* prob, int32_t* next_flat,
+                                 int8_t* reward, uint8_t* done);
 /* HOST output: prob[c*3+k] = slip-combination weight c (0: no slip, 1: B slips, 2: A slips,
  * 3: both; :211-222, evaluated left to right in float64) times outcome probability 1, 0.5, 0.25
  * (k = 0,1,2; :326-360).  prob_code values index this table (:241). */

@@ -224,6 +224,85 @@ def test_single_agent_mode_matches_reference_tables(learner):
     env.close()
 
 
+TABLES = sorted(glob.glob(os.path.join(GOLDEN, "table_*.npz")))
+
+
+@pytest.mark.parametrize("path", TABLES, ids=[os.path.basename(p)[:-4] for p in TABLES])
+def test_device_enumerated_transition_table_equals_reference_row_for_row(path):
+    """soccer_enumerate_transitions (the kernels' own rule functions, run over every state tuple x joint
+    action) against the reference's complete P_readable: list order, float64 probabilities, next tuple,
+    reward, done."""
+    from gym_soccer_littman94_amd import SoccerBatch
+    g = np.load(path)
+    b = SoccerBatch(1, int(g["width"]), int(g["height"]), float(g["slip"]))
+    count, prob, nxt, rew, done = b.transitions()
+    W = int(g["width"]) + 2; H = int(g["height"])
+    rows, gp = g["rows"], g["prob"]          # xa,ya,xb,yb,p, aa,ab, k, nxa,nya,nxb,nyb,np, reward, done
+    r64 = rows.astype(np.int64)
+    flat = (((r64[:, 0] * W + r64[:, 1]) * H + r64[:, 2]) * W + r64[:, 3]) * 2 + r64[:, 4]
+    nflat = (((r64[:, 8] * W + r64[:, 9]) * H + r64[:, 10]) * W + r64[:, 11]) * 2 + r64[:, 12]
+    ja = r64[:, 5] * 5 + r64[:, 6]; k = r64[:, 7]
+    np.testing.assert_array_equal(prob[flat, ja, k], gp)                      # bit-exact float64
+    np.testing.assert_array_equal(nxt[flat, ja, k], nflat)
+    np.testing.assert_array_equal(rew[flat, ja, k], rows[:, 13])
+    np.testing.assert_array_equal(done[flat, ja, k], rows[:, 14])
+    # list lengths: total entries and per-key counts agree, unreachable tuples have no key
+    assert int(count[count > 0].sum()) == len(rows)
+    last = np.append(k[1:] == 0, True)
+    np.testing.assert_array_equal(count[flat[last], ja[last]], k[last] + 1)
+    np.testing.assert_array_equal(count[:, 0] < 0, g["kind"] == 0)
+    b.close()
+
+
+def test_facade_tables_have_the_reference_shape_and_quirks(slip_env):
+    g = np.load(os.path.join(GOLDEN, "table_5x4_s0p2.npz"))
+    env = slip_env
+    PR, P, Pmat, Rmat = env.P_readable, env.P, env.Pmat, env.Rmat
+    assert len(PR) == 920 and len(P) == 761 and Pmat.shape == (761, 761, 5, 5) and Rmat.shape == (761, 5, 5)
+    tr = PR[(1, 2, 1, 3, 0)][('EAST', 'WEST')]
+    assert isinstance(tr[0][0], float) and isinstance(tr[0][1], tuple) and isinstance(tr[0][3], bool)
+    assert [t[0] for t in tr][:2] == [0.32000000000000006, 0.32000000000000006]
+    assert P[241][(3, 4)][0][1] in (241, 242)
+    assert abs(Pmat[0, 0, 0, 0] - 160.0) < 1e-9             # one unit per goal tuple (SURVEY Appendix D)
+    np.testing.assert_allclose(Pmat[1:].sum(axis=1), 1.0, atol=1e-12)
+    assert abs(Rmat).max() <= 1.0 and Rmat[0].max() == 0
+    # spot-check against the golden rows
+    rows, gp = g["rows"], g["prob"]
+    for i in np.random.RandomState(0).choice(len(rows), 500, replace=False):
+        st = tuple(int(x) for x in rows[i, :5]); key = (env.ACTION_STRING[rows[i, 5]], env.ACTION_STRING[rows[i, 6]])
+        p_, ns_, r_, d_ = PR[st][key][int(rows[i, 7])]
+        assert p_ == gp[i] and ns_ == tuple(int(x) for x in rows[i, 8:13]) and r_ == rows[i, 13] and d_ == bool(rows[i, 14])
+
+
+def test_reference_style_planner_runs_on_our_tables():
+    """Value iteration in the reference's formulation (gym_soccer/utils/planners.py:4-18 reads env.P only)
+    against a stand-still opponent: the best response must score every episode (tests/test_general.py:304+)."""
+    stand = {s: 0 for s in range(761)}
+    env = SoccerSimultaneousEnv(width=5, height=4, slip_prob=0.0, player_b_policy=stand)
+    P = env.P
+    V = np.zeros(len(P)); gamma = 0.99
+    for _ in range(200):
+        Q = np.zeros((len(P), 5))
+        for s_ in range(len(P)):
+            for a in range(5):
+                for pr, ns, r, d in P[s_][a]:
+                    Q[s_, a] += pr * (r + gamma * V[ns] * (not d))
+        if np.max(np.abs(V - Q.max(1))) < 1e-10:
+            break
+        V = Q.max(1)
+    pi = Q.argmax(1)
+    wins = 0
+    for ep in range(50):
+        o, _ = env.reset()
+        for _ in range(100):
+            o, r, d, t, _ = env.step({'player_a': int(pi[o['player_a']])})
+            if d['player_a'] or t['player_a']:
+                wins += r['player_a'] == 1.0
+                break
+    assert wins == 50
+    env.close()
+
+
 def test_slip_probabilities_show_up_in_info_p(slip_env):
     seen = set()
     for _ in range(400):
