@@ -36,7 +36,8 @@ class RolloutArgs(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("sample_actions", C.c_int32), ("act_a", C.c_void_p),
                 ("act_b", C.c_void_p), ("act_stride", C.c_int64), ("obs", C.c_void_p),
                 ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
-                ("out_stride", C.c_int64), ("return_sum", C.c_void_p), ("episode_count", C.c_void_p)]
+                ("out_stride", C.c_int64), ("return_sum", C.c_void_p), ("episode_count", C.c_void_p),
+                ("mix_a", C.c_void_p), ("mix_b", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/soccer_hip.h declares

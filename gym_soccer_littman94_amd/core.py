@@ -168,11 +168,21 @@ class SoccerBatch:
 
     def rollout(self, n_steps, act_a=None, act_b=None, act_stride=0, sample_actions=False, obs=None,
                 reward=None, terminated=None, truncated=None, out_stride=0, return_sum=None,
-                episode_count=None):
+                episode_count=None, mix_a=None, mix_b=None):
         a = RolloutArgs(int(n_steps), 1 if sample_actions else 0, _ptr(act_a), _ptr(act_b), int(act_stride),
                         _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated), int(out_stride),
-                        _ptr(return_sum), _ptr(episode_count))
+                        _ptr(return_sum), _ptr(episode_count), _ptr(mix_a), _ptr(mix_b))
         self._check(self.lib.batched_rollout(self.h, C.byref(a)))
+
+    @staticmethod
+    def mixed_policy_thresholds(probs):
+        """[nS, 5] action probabilities -> uint16[nS, 4] cumulative thresholds for batched_rollout's
+        mix_a / mix_b (deterministic: floor(cumsum * 65536), clipped)."""
+        p = np.asarray(probs, dtype=np.float64)
+        assert p.ndim == 2 and p.shape[1] == 5 and (p >= 0).all() and np.allclose(p.sum(1), 1.0), \
+            "probs must be [n_states, 5] rows summing to 1"
+        c = np.cumsum(p, axis=1)[:, :4]
+        return np.ascontiguousarray(np.clip(np.floor(c * 65536.0), 0, 65535).astype(np.uint16))
 
     def set_policy(self, player, policy):
         """Fixed policy for 'player_a' / 'player_b' (dict or sequence: observation index -> action), or None."""

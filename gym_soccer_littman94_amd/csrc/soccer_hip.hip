@@ -370,8 +370,9 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
     const bool any_out = a->obs || a->reward || a->terminated || a->truncated;
     if (any_out && a->out_stride < (int64_t)h->P.n)
         return fail(h, SOCCER_E_INVALID, "batched_rollout: out_stride must be >= n_lanes");
-    if (!aligned(a->obs, 2) || !aligned(a->return_sum, 4) || !aligned(a->episode_count, 4))
-        return fail(h, SOCCER_E_INVALID, "batched_rollout: misaligned obs/return_sum/episode_count");
+    if (!aligned(a->obs, 2) || !aligned(a->return_sum, 4) || !aligned(a->episode_count, 4) ||
+        !aligned(a->mix_a, 8) || !aligned(a->mix_b, 8))
+        return fail(h, SOCCER_E_INVALID, "batched_rollout: misaligned obs/return_sum/episode_count/mix_*");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     int E = h->E;
     auto ok = [&](int e) {
@@ -389,7 +390,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
         KernelParams P = h->P;
         bind_tick(h, P, (uint64_t)ns);
         const long long ao = (long long)s0 * a->act_stride, oo = (long long)s0 * a->out_stride;
-        RolloutIO io{ns, a->sample_actions, a->act_a ? a->act_a + ao : nullptr, a->act_b ? a->act_b + ao : nullptr,
+        RolloutIO io{ns, a->sample_actions, a->mix_a, a->mix_b, a->act_a ? a->act_a + ao : nullptr, a->act_b ? a->act_b + ao : nullptr,
                      (long long)a->act_stride, a->obs ? a->obs + oo : nullptr, a->reward ? a->reward + oo : nullptr,
                      a->terminated ? a->terminated + oo : nullptr, a->truncated ? a->truncated + oo : nullptr,
                      (long long)a->out_stride, a->return_sum, a->episode_count};

@@ -69,6 +69,7 @@ struct ResetIO {
 
 struct RolloutIO {
     int32_t n_steps; int32_t sample_actions;
+    const uint16_t* mix_a; const uint16_t* mix_b;   // [nS][4] cumulative 16-bit thresholds of a mixed policy, or nullptr
     const int8_t* act_a; const int8_t* act_b; long long act_stride;
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated; long long out_stride;
     int32_t* return_sum; int32_t* episode_count;
@@ -680,7 +681,9 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         if (IO.act_a) aa.load(IO.act_a, i0);
         if (IO.act_b) ab.load(IO.act_b, i0);
     }
-    const bool fixed = P.policy_a != nullptr || P.policy_b != nullptr;      // single-agent mode
+    // the observation of the current tuple is carried along when an action depends on it
+    const bool fixed = P.policy_a != nullptr || P.policy_b != nullptr ||    // single-agent mode
+                       (IO.sample_actions && (IO.mix_a != nullptr || IO.mix_b != nullptr));
     uint32_t s_now[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) s_now[j] = fixed ? obs_of(T, P, S.L[j].A, S.L[j].B, S.L[j].p) : 0u;
@@ -700,9 +703,18 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         for (int j = 0; j < E; ++j) {
             const Draw d = draw_from_word(words[j]);
             uint32_t a = aa.get(j), b = ab.get(j);
-            if (IO.sample_actions) {                    // two uniform actions from one 32-bit word
-                a = ((awords[j] & 0xffffu) * 5u) >> 16;
-                b = ((awords[j] >> 16) * 5u) >> 16;
+            if (IO.sample_actions) {                    // two actions from one 32-bit word, 16 bits each
+                const uint32_t ha = awords[j] & 0xffffu, hb = awords[j] >> 16;
+                a = (ha * 5u) >> 16;                    // uniform
+                b = (hb * 5u) >> 16;
+                if (IO.mix_a) {                         // mixed policy: first action whose cumulative threshold exceeds the draw
+                    const uint2 th = *reinterpret_cast<const uint2*>(IO.mix_a + 4u * s_now[j]);
+                    a = (ha >= (th.x & 0xffffu)) + (ha >= (th.x >> 16)) + (ha >= (th.y & 0xffffu)) + (ha >= (th.y >> 16));
+                }
+                if (IO.mix_b) {
+                    const uint2 th = *reinterpret_cast<const uint2*>(IO.mix_b + 4u * s_now[j]);
+                    b = (hb >= (th.x & 0xffffu)) + (hb >= (th.x >> 16)) + (hb >= (th.y & 0xffffu)) + (hb >= (th.y >> 16));
+                }
             }
             if (fixed) {
                 if (P.policy_a) a = (uint32_t)(uint8_t)P.policy_a[s_now[j]];

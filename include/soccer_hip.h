@@ -127,6 +127,12 @@ typedef struct soccer_rollout_args {
     int64_t        out_stride;
     int32_t*       return_sum;  /* [n] += sum of A's rewards over the T steps, or NULL */
     int32_t*       episode_count; /* [n] += episodes finished during the T steps, or NULL */
+    /* sample_actions only: mixed (stochastic) policies, DEVICE uint16[n_states][4].  Row s holds the
+     * cumulative probabilities of actions 0..3 at observation s scaled to 0..65535 (action 4 takes the
+     * rest); the action is the number of thresholds <= the player's 16-bit draw (player A: w & 0xffff,
+     * player B: w >> 16).  NULL: uniform.  This is the self-play rollout of BASELINE config 5. */
+    const uint16_t* mix_a;
+    const uint16_t* mix_b;
 } soccer_rollout_args;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

@@ -52,6 +52,8 @@ def lib():
         L.soc_oracle_batched_step.restype = C.c_int64
         L.soc_oracle_sample_actions.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64,
                                                 C.c_void_p, C.c_void_p]
+        L.soc_oracle_sample_actions_mixed.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -164,4 +166,12 @@ class Oracle:
         a = np.zeros(self.n, np.int8); b = np.zeros(self.n, np.int8)
         self.L.soc_oracle_sample_actions(self.n, self.seed, self.lane_offset,
                                          self.tick if tick is None else tick, _p(a), _p(b))
+        return a, b
+
+    def sample_actions_mixed(self, obs_now, mix_a=None, mix_b=None):
+        a = np.zeros(self.n, np.int8); b = np.zeros(self.n, np.int8)
+        o = np.ascontiguousarray(obs_now, np.uint16)
+        ma = None if mix_a is None else np.ascontiguousarray(mix_a, np.uint16)
+        mb = None if mix_b is None else np.ascontiguousarray(mix_b, np.uint16)
+        self.L.soc_oracle_sample_actions_mixed(self.n, self.seed, self.lane_offset, self.tick, _p(o), _p(ma), _p(mb), _p(a), _p(b))
         return a, b

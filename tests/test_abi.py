@@ -28,11 +28,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.soccer_abi_version() == 1
 
 
-def test_struct_layouts_match_header():
-    # sizes the C compiler gives these structs on x86-64 (checked against the header by field count)
-    assert C.sizeof(_lib.Config) == 64
-    assert C.sizeof(_lib.StepArgs) == 11 * 8
-    assert C.sizeof(_lib.RolloutArgs) == 8 + 2 * 8 + 8 + 4 * 8 + 8 + 2 * 8
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors of the ABI structs have the size and field offsets the C compiler gives the header."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text("""
+#include <stdio.h>
+#include <stddef.h>
+#include "soccer_hip.h"
+int main(void) {
+    printf("%zu %zu %zu\\n", sizeof(soccer_config), sizeof(soccer_step_args), sizeof(soccer_rollout_args));
+    printf("%zu %zu %zu %zu\\n", offsetof(soccer_config, slip_prob), offsetof(soccer_config, seed),
+           offsetof(soccer_config, flags), offsetof(soccer_config, stream));
+    printf("%zu %zu %zu\\n", offsetof(soccer_rollout_args, act_stride), offsetof(soccer_rollout_args, out_stride),
+           offsetof(soccer_rollout_args, mix_a));
+    return 0;
+}
+""")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    got = [int(x) for x in out]
+    Cfg, St, Ro = _lib.Config, _lib.StepArgs, _lib.RolloutArgs
+    assert got == [C.sizeof(Cfg), C.sizeof(St), C.sizeof(Ro),
+                   Cfg.slip_prob.offset, Cfg.seed.offset, Cfg.flags.offset, Cfg.stream.offset,
+                   Ro.act_stride.offset, Ro.out_stride.offset, Ro.mix_a.offset]
 
 
 @pytest.mark.parametrize("kw,msg", [

@@ -320,6 +320,37 @@ def test_rollout_equals_successive_steps_and_sampled_actions_match_oracle():
         b.close()
 
 
+def test_config5_selfplay_rollout_histogram_matches_cpu_exactly():
+    """BASELINE config 5: 2^20 lanes x 100-step horizon, both players sampling from mixed policy tables
+    in-kernel (per-lane Philox), reward histogram compared with the CPU oracle — exact counts, since
+    every lane is bit-exact.  (The reference has no Minimax-Q; the policies here are random mixed
+    strategies of the shape a Minimax-Q learner would hold: [nS, 5] per player.)"""
+    n, T = 1 << 20, 100
+    rng = np.random.default_rng(94)
+    probs_a = rng.dirichlet(np.ones(5) * 0.7, size=761); probs_b = rng.dirichlet(np.ones(5) * 0.7, size=761)
+    ta = SoccerBatch.mixed_policy_thresholds(probs_a); tb = SoccerBatch.mixed_policy_thresholds(probs_b)
+    b = SoccerBatch(n, 5, 4, 0.0, seed=1994, autoreset=True)
+    o = Oracle(5, 4, 0.0, n=n, seed=1994, autoreset=True)
+    obs0 = b.alloc(n, np.uint16); b.reset(obs=obs0)
+    cur = o.reset()
+    np.testing.assert_array_equal(obs0.download(), cur)
+    da = b.alloc(ta.shape, np.uint16).upload(ta); db = b.alloc(tb.shape, np.uint16).upload(tb)
+    rs = b.alloc(n, np.int32).fill(0); ec = b.alloc(n, np.int32).fill(0)
+    b.reset_stats()
+    b.rollout(T, sample_actions=True, mix_a=da, mix_b=db, return_sum=rs, episode_count=ec)
+    ret = np.zeros(n, np.int64); eps = np.zeros(n, np.int64)
+    for k in range(T):
+        a, bb = o.sample_actions_mixed(cur, ta, tb)
+        c = o.step(a, bb)
+        ret += c["reward"]; eps += (c["terminated"] | c["truncated"]); cur = c["obs"]
+    hist = b.stats()[0]
+    np.testing.assert_array_equal(hist, o.hist)
+    np.testing.assert_array_equal(rs.download(), ret); np.testing.assert_array_equal(ec.download(), eps)
+    assert_state_equal(b, o)
+    assert hist.sum() > 2 * n and hist[0] > 0 and hist[2] > 0
+    b.close()
+
+
 def test_results_do_not_depend_on_sharding_or_vector_width():
     """Lanes [0,N) on one handle == two handles of N/2 with lane_offset (multi-GPU contract)."""
     n, T = 16384, 40
