@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libsoccer_hip.so")
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE = 0, -1, -2, -3, -4
 F_AUTORESET = 1
 F_NULL_STREAM = 2
+F_HOST_MAPPED = 4
 
 
 class SoccerHipError(RuntimeError):
@@ -56,6 +57,7 @@ PROTOTYPES = {
     "batched_step_host": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
     "batched_reset_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "soccer_set_policy": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "soccer_host_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "soccer_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "soccer_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "soccer_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),

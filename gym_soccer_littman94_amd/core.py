@@ -80,7 +80,7 @@ class SoccerBatch:
     """
 
     def __init__(self, n_lanes, width=5, height=4, slip_prob=0.0, seed=0, autoreset=False,
-                 max_steps=100, device=0, lane_offset=0, stream=None, envs_per_thread=0):
+                 max_steps=100, device=0, lane_offset=0, stream=None, envs_per_thread=0, host_mapped=False):
         """stream: None -> the handle creates its own HIP stream; an integer hipStream_t -> enqueue on
         that stream (0 = the device's default/null stream, which is what torch's default stream is)."""
         self.lib = _lib.load()
@@ -88,7 +88,8 @@ class SoccerBatch:
         cfg = Config(n_lanes=int(n_lanes), width=int(width), height=int(height),
                      slip_prob=float(slip_prob), max_steps=int(max_steps), device=int(device),
                      seed=int(seed) & 0xFFFFFFFFFFFFFFFF, lane_offset=int(lane_offset),
-                     flags=(_lib.F_AUTORESET if autoreset else 0) | (_lib.F_NULL_STREAM if stream == 0 else 0),
+                     flags=(_lib.F_AUTORESET if autoreset else 0) | (_lib.F_NULL_STREAM if stream == 0 else 0) |
+                     (_lib.F_HOST_MAPPED if host_mapped else 0),
                      envs_per_thread=int(envs_per_thread), stream=stream or None)
         h = C.c_void_p()
         _lib.check(self.lib, None, self.lib.soccer_create(C.byref(cfg), C.byref(h)))
@@ -220,6 +221,14 @@ class SoccerBatch:
                         out["final_obs"].ctypes.data, None)
         self._check(self.lib.batched_step_host(self.h, C.byref(args)))
         return out
+
+    def host_state_view(self):
+        """host_mapped handles: numpy uint8 view [6, n] over the pinned state streams (row_a, col_a, row_b,
+        col_b, poss | needs_reset << 1, t) the GPU works on in place.  Touch it only while the stream is idle."""
+        p = C.c_void_p(); stride = C.c_uint64()
+        self._check(self.lib.soccer_host_view(self.h, C.byref(p), C.byref(stride)))
+        buf = (C.c_uint8 * (6 * stride.value)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(6, stride.value)[:, :self.n]
 
     # -- state injection / readback -----------------------------------------------------------
     def set_state(self, row_a=None, col_a=None, row_b=None, col_b=None, poss=None, t=None, needs_reset=None):

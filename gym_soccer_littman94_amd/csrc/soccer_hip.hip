@@ -43,6 +43,7 @@ struct soccer_handle {
     size_t state_stride = 0;                // bytes between consecutive streams
     uint8_t* stage_dev = nullptr;           // staging for the host-pointer entry points
     uint8_t* stage_host = nullptr;          // pinned
+    bool mapped = false;                    // SOCCER_F_HOST_MAPPED: d_state and the staging block are pinned host memory
     size_t stage_bytes = 0;
     int tick_slot = 0;                      // slot the NEXT launch reads
     uint64_t tick = 0;                      // host mirror of the device tick
@@ -92,6 +93,7 @@ static void free_handle(soccer_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
     void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -159,15 +161,26 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     const size_t n = cfg->n_lanes;
     const size_t padded = (n + 255) & ~size_t(255);
     h->state_stride = padded;
-    CREATE_TRY(hipMalloc(&h->d_state, 6 * padded));
+    h->mapped = (cfg->flags & SOCCER_F_HOST_MAPPED) != 0;
+    if (h->mapped) {
+        if (n > 4096) { free_handle(h); return fail(nullptr, SOCCER_E_INVALID, "SOCCER_F_HOST_MAPPED is for small handles (n_lanes <= 4096)"); }
+        CREATE_TRY(hipHostMalloc(&h->d_state, 6 * padded, hipHostMallocMapped));
+    } else {
+        CREATE_TRY(hipMalloc(&h->d_state, 6 * padded));
+    }
     P.state = h->d_state; P.state_stride = padded;
     // every lane starts needing a reset (:140), parked on the first ISD state so the tuple is valid
+    if (h->mapped) {
+        const uint8_t init[6] = {(uint8_t)R.isd[0][0], (uint8_t)R.isd[0][1], (uint8_t)R.isd[0][2], (uint8_t)R.isd[0][3], (uint8_t)(2 | R.isd[0][4]), 0};
+        for (int k = 0; k < 6; ++k) std::memset(h->d_state + k * padded, init[k], padded);
+    } else {
     CREATE_TRY(hipMemsetAsync(h->d_state, R.isd[0][0], padded, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_state + padded, R.isd[0][1], padded, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_state + 2 * padded, R.isd[0][2], padded, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_state + 3 * padded, R.isd[0][3], padded, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_state + 4 * padded, 2 | R.isd[0][4], padded, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_state + 5 * padded, 0, padded, h->stream));
+    }
 
     CREATE_TRY(hipMalloc(&h->d_nc, R.next_cell.size() * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&h->d_isd, sizeof(R.isd_words)));
@@ -416,7 +429,8 @@ extern "C" int soccer_set_state(soccer_handle* h, const int8_t* row_a, const int
     const Rules& R = h->rules;
     // current device copy of whatever is not supplied, so the resulting tuple can be validated
     std::vector<uint8_t> img(6 * S);
-    HIP_TRY(h, hipMemcpy(img.data(), h->d_state, 6 * S, hipMemcpyDeviceToHost));
+    if (h->mapped) std::memcpy(img.data(), h->d_state, 6 * S);
+    else HIP_TRY(h, hipMemcpy(img.data(), h->d_state, 6 * S, hipMemcpyDeviceToHost));
     int8_t* ra = reinterpret_cast<int8_t*>(img.data());
     int8_t* ca = ra + S; int8_t* rb = ra + 2 * S; int8_t* cb = ra + 3 * S;
     uint8_t* ps = img.data() + 4 * S; uint8_t* tt = img.data() + 5 * S;
@@ -437,7 +451,15 @@ extern "C" int soccer_set_state(soccer_handle* h, const int8_t* row_a, const int
             return fail(h, SOCCER_E_INVALID, "lane %zu: state (%d, %d, %d, %d, %d) is not a reachable state tuple",
                         i, (int)ra[i], (int)ca[i], (int)rb[i], (int)cb[i], (int)p);
     }
-    HIP_TRY(h, hipMemcpy(h->d_state, img.data(), 6 * S, hipMemcpyHostToDevice));
+    if (h->mapped) std::memcpy(h->d_state, img.data(), 6 * S);
+    else HIP_TRY(h, hipMemcpy(h->d_state, img.data(), 6 * S, hipMemcpyHostToDevice));
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_host_view(soccer_handle* h, uint8_t** state, uint64_t* stride) {
+    if (!h || !state || !stride) return fail(h, SOCCER_E_INVALID, "handle/state/stride is NULL");
+    if (!h->mapped) return fail(h, SOCCER_E_STATE, "soccer_host_view needs a SOCCER_F_HOST_MAPPED handle");
+    *state = h->d_state; *stride = h->state_stride;
     return SOCCER_OK;
 }
 
@@ -449,7 +471,8 @@ extern "C" int soccer_get_state(soccer_handle* h, int8_t* row_a, int8_t* col_a, 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const size_t n = h->P.n, S = h->state_stride;
     std::vector<uint8_t> img(6 * S);
-    HIP_TRY(h, hipMemcpy(img.data(), h->d_state, 6 * S, hipMemcpyDeviceToHost));
+    if (h->mapped) std::memcpy(img.data(), h->d_state, 6 * S);
+    else HIP_TRY(h, hipMemcpy(img.data(), h->d_state, 6 * S, hipMemcpyDeviceToHost));
     if (row_a) std::memcpy(row_a, img.data(), n);
     if (col_a) std::memcpy(col_a, img.data() + S, n);
     if (row_b) std::memcpy(row_b, img.data() + 2 * S, n);
@@ -491,8 +514,13 @@ StageLayout stage_layout(size_t n) {
 }
 int ensure_stage(soccer_handle* h, const StageLayout& L) {
     if (h->stage_bytes >= L.total) return SOCCER_OK;
-    HIP_TRY(h, hipMalloc(&h->stage_dev, L.total));
-    HIP_TRY(h, hipHostMalloc(&h->stage_host, L.total, hipHostMallocDefault));
+    if (h->mapped) {            // the kernel reads inputs from / writes outputs to the pinned block in place
+        HIP_TRY(h, hipHostMalloc(&h->stage_host, L.total, hipHostMallocMapped));
+        h->stage_dev = h->stage_host;
+    } else {
+        HIP_TRY(h, hipMalloc(&h->stage_dev, L.total));
+        HIP_TRY(h, hipHostMalloc(&h->stage_host, L.total, hipHostMallocDefault));
+    }
     h->stage_bytes = L.total;
     return SOCCER_OK;
 }
@@ -512,7 +540,7 @@ extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {
     if (a->act_b) std::memcpy(H + L.act_b, a->act_b, n);
     if (a->u_step) std::memcpy(H + L.u_step, a->u_step, 8 * n);
     if (a->u_reset) std::memcpy(H + L.u_reset, a->u_reset, 8 * n);
-    HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
+    if (!h->mapped) HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
     soccer_step_args d{};
     d.act_a = a->act_a ? reinterpret_cast<const int8_t*>(D + L.act_a) : nullptr;
     d.act_b = a->act_b ? reinterpret_cast<const int8_t*>(D + L.act_b) : nullptr;
@@ -523,7 +551,7 @@ extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {
     d.prob_code = D + L.code;
     if (a->last_return) return fail(h, SOCCER_E_INVALID, "batched_step_host: last_return is device-only");
     if (int rc = batched_step_ex(h, &d)) return rc;
-    HIP_TRY(h, hipMemcpyAsync(H + L.in_bytes, D + L.in_bytes, L.total - L.in_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (!h->mapped) HIP_TRY(h, hipMemcpyAsync(H + L.in_bytes, D + L.in_bytes, L.total - L.in_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (a->obs) std::memcpy(a->obs, H + L.obs, 2 * n);
     if (a->final_obs) std::memcpy(a->final_obs, H + L.final_obs, 2 * n);
@@ -544,11 +572,11 @@ extern "C" int batched_reset_host(soccer_handle* h, const uint8_t* mask, const d
     uint8_t* H = h->stage_host; uint8_t* D = h->stage_dev;
     if (mask) std::memcpy(H + L.mask, mask, n);
     if (u_reset) std::memcpy(H + L.u_reset, u_reset, 8 * n);
-    if (mask || u_reset) HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
+    if ((mask || u_reset) && !h->mapped) HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
     if (int rc = batched_reset(h, mask ? D + L.mask : nullptr,
                                u_reset ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr,
                                reinterpret_cast<uint16_t*>(D + L.obs))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(H + L.obs, D + L.obs, 2 * n, hipMemcpyDeviceToHost, h->stream));
+    if (!h->mapped) HIP_TRY(h, hipMemcpyAsync(H + L.obs, D + L.obs, 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (obs) std::memcpy(obs, H + L.obs, 2 * n);
     return SOCCER_OK;

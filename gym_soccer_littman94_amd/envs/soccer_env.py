@@ -38,7 +38,11 @@ class SoccerSimultaneousEnv:
             "Both players cannot have a policy. At least one must be None."
         assert width >= 5, "Width must be at least 5 columns."
         assert height >= 4, "Height must be at least 4 rows."
-        self._batch = SoccerBatch(1, width, height, slip_prob, seed=seed, autoreset=False, device=device)
+        # one lane whose state and I/O staging live in pinned host memory the GPU accesses in place:
+        # a step is one kernel launch + one stream sync, no copies
+        self._batch = SoccerBatch(1, width, height, slip_prob, seed=seed, autoreset=False, device=device,
+                                  host_mapped=True)
+        self._sv = self._batch.host_state_view()
         # single-agent mode: the fixed side's policy lives on the device and is looked up by the kernel
         if player_a_policy is not None:
             self._batch.set_policy('player_a', player_a_policy)
@@ -164,12 +168,14 @@ class SoccerSimultaneousEnv:
         st = tuple(int(x) for x in self.state)
         if st == self.TERMINAL_STATE or (st not in self.state_space and st not in self.goal_states):
             raise KeyError(st)                      # P_readable[self.state] in the reference (:394)
-        self._batch.set_state([st[0]], [st[1]], [st[2]], [st[3]], [st[4]],
-                              t=[min(max(int(self.timestep), 0), self._batch.max_steps)], needs_reset=[0])
+        sv = self._sv
+        sv[0, 0], sv[1, 0], sv[2, 0], sv[3, 0] = st[0], st[1], st[2], st[3]
+        sv[4, 0] = st[4]                                # needs_reset bit cleared
+        sv[5, 0] = min(max(int(self.timestep), 0), self._batch.max_steps)
 
     def _pull_state(self):
-        s = self._batch.get_state()
-        self.state = (int(s["row_a"][0]), int(s["col_a"][0]), int(s["row_b"][0]), int(s["col_b"][0]), int(s["poss"][0]))
+        sv = self._sv
+        self.state = (int(sv[0, 0]), int(sv[1, 0]), int(sv[2, 0]), int(sv[3, 0]), int(sv[4, 0]) & 1)
 
     def reset(self, seed=None, options=None):
         if seed is not None:

@@ -66,6 +66,8 @@ extern "C" {
 /* cfg.flags */
 #define SOCCER_F_AUTORESET   1u  /* lanes that terminate/truncate are reset inside the same step */
 #define SOCCER_F_NULL_STREAM 2u  /* enqueue on the device's default (null) stream; cfg.stream ignored */
+#define SOCCER_F_HOST_MAPPED 4u  /* small handles (single-env facade): state and staging live in pinned host memory
+                                    the GPU reads/writes in place, so the *_host calls and state access copy nothing */
 
 /* actions (soccer_simultaneous_env.py:8-12); moves are (dcol,drow) (:24-30) */
 #define SOCCER_NOOP  0
@@ -173,6 +175,11 @@ int batched_reset_host(soccer_handle* h, const uint8_t* mask, const double* u_re
  * side may have a policy (:38).  policy NULL clears it.  Rewards stay player A's (+1 A scores); a
  * learner-B host negates them as the reference's table does (:243-244). */
 int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_host, int32_t n_states);
+
+/* SOCCER_F_HOST_MAPPED handles only: HOST address of the six state streams (row_a, col_a, row_b, col_b,
+ * poss|needs_reset<<1, t; `stride` bytes apart).  Valid to read/write whenever the stream is idle
+ * (after a *_host call or soccer_sync); writes bypass the tuple validation of soccer_set_state. */
+int soccer_host_view(soccer_handle* h, uint8_t** state, uint64_t* stride);
 
 /* ---- state injection / readback (`env.state = tuple`, tests/test_deterministic...py:43) -- */
 /* HOST pointers of n_lanes elements; any pointer may be NULL (field left unchanged / not read).
