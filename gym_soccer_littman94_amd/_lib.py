@@ -13,6 +13,7 @@ OK, E_INVALID, E_HIP, E_NOMEM, E_STATE = 0, -1, -2, -3, -4
 F_AUTORESET = 1
 F_NULL_STREAM = 2
 F_HOST_MAPPED = 4
+F_STEP_STATS = 8
 
 
 class SoccerHipError(RuntimeError):

@@ -200,6 +200,7 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     P.nc_len = static_cast<int32_t>(R.next_cell.size());
     P.max_steps = cfg->max_steps;
     P.autoreset = (cfg->flags & SOCCER_F_AUTORESET) ? 1u : 0u;
+    P.step_stats = (cfg->flags & SOCCER_F_STEP_STATS) ? 1u : 0u;
     P.isd_shift = R.n_isd == 4 ? 0u : 1u;
     // slip-combination weights exactly as the reference writes them, left to right in float64 (:211-222)
     {

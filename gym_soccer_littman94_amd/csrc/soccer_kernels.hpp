@@ -52,6 +52,7 @@ struct KernelParams {
     int32_t W, HW, HW5, nc_len, lut_len;   // HW5 = 5*H*W
     int32_t max_steps;
     uint32_t autoreset;
+    uint32_t step_stats;                  // batched_step feeds the episode histogram (SOCCER_F_STEP_STATS)
     uint32_t isd_shift;                   // 2 - log2(n_isd): index = two random bits >> isd_shift
     double w[4];                          // slip-combination weights c0..c3 (:211-222)
 };
@@ -554,7 +555,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
     const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
     const unsigned long long tick = *P.tick_in;                 // scalar load
     if (P.tick_out) publish_tick(P, tick, 1ull);
-    HistAcc<true> hist; hist.init(P);
+    // the episode histogram of single steps is opt-in (SOCCER_F_STEP_STATS): counting, the wave
+    // reduction and the slot update cost ~0.5 us of a ~9 us launch
+    const bool stats = P.step_stats != 0u;
+    HistAcc<true> hist; hist.fp = 0u; hist.ng = 0u; hist.old01 = make_ulonglong2(0ull, 0ull); hist.old2 = 0ull;
+    if (stats) hist.init(P);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
     bool mis = false;
     for (unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; g < groups; g += stride) {
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
             o_lo = __builtin_amdgcn_alignbit(o_hi, o_lo, 16); o_hi = (o_hi >> 16) | (R.obs << 16);
             f_lo = __builtin_amdgcn_alignbit(f_hi, f_lo, 16); f_hi = (f_hi >> 16) | (R.final_obs << 16);
             fin_mask |= R.finished << j;
-            hist.add(R.finished, R.reward);
+            if (stats) hist.add(R.finished, R.reward);
         }
         if (!VEC && cnt < 4) {               // ragged tail: the shifted-in bytes sit at the top
             const int sh = 8 * (4 - cnt);
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
         }
     }
     if (mis) *P.misuse = 1u;
-    hist.flush(P);
+    if (stats) hist.flush(P);
 }
 
 // =================================================================================================

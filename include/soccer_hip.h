@@ -66,6 +66,8 @@ extern "C" {
 /* cfg.flags */
 #define SOCCER_F_AUTORESET   1u  /* lanes that terminate/truncate are reset inside the same step */
 #define SOCCER_F_NULL_STREAM 2u  /* enqueue on the device's default (null) stream; cfg.stream ignored */
+#define SOCCER_F_STEP_STATS  8u  /* batched_step also feeds the episode histogram (soccer_get_stats); off by
+                                    default: it costs ~5 % of a launch.  batched_rollout always counts. */
 #define SOCCER_F_HOST_MAPPED 4u  /* small handles (single-env facade): state and staging live in pinned host memory
                                     the GPU reads/writes in place, so the *_host calls and state access copy nothing */
 
@@ -212,7 +214,8 @@ int soccer_enumerate_transitions(soccer_handle* h, int32_t* count, double* prob,
 int soccer_prob_table(const soccer_handle* h, double prob[12]);
 
 /* ---- episode statistics ------------------------------------------------------------------ */
-/* hist[0..2] = episodes finished with A's return -1, 0, +1 since create / soccer_reset_stats;
+/* hist[0..2] = episodes finished with A's return -1, 0, +1 since create / soccer_reset_stats, counted by
+ * batched_rollout and — on handles created with SOCCER_F_STEP_STATS — by batched_step;
  * misuse = nonzero if any lane was stepped while it needed reset (the reference's assert, :376;
  * such lanes are left untouched).  Synchronises the stream. HOST outputs. */
 int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* misuse);

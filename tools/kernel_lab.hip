@@ -190,7 +190,7 @@ int main(int argc, char** argv) {
     P.state = d_state; P.state_stride = padded; P.lut = d_lut; P.lut_len = (int)R.lut.size(); P.next_cell = d_nc; P.isd = d_isd;
     P.tick_in = d_tick; P.tick_out = d_tick + 16; P.key0 = 1; P.key1 = 2; P.lane_offset = 0;
     P.hist = d_hist; P.misuse = d_mis; P.first = 0; P.n = N; P.W = R.W; P.HW = R.H * R.W; P.HW5 = 5 * R.H * R.W;
-    P.nc_len = (int)R.next_cell.size(); P.max_steps = 100; P.autoreset = 1; P.isd_shift = 0;
+    P.nc_len = (int)R.next_cell.size(); P.max_steps = 100; P.autoreset = 1; P.step_stats = 0; P.isd_shift = 0;
     P.w[0] = 1; P.w[1] = P.w[2] = P.w[3] = 0;
     const size_t smem = (kIsdWords + R.next_cell.size()) * 4 + R.lut.size() * 2;
     // actions: T rows cycled
@@ -218,6 +218,7 @@ int main(int argc, char** argv) {
     add("rolled E4 LDS nohist     ", [&] { hipLaunchKernelGGL((k_step_rolled<true, false>), dim3(1024), dim3(256), smem, st, P, io_for(step)); });
     add("rolled E4 global hist    ", [&] { hipLaunchKernelGGL((k_step_rolled<false, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step (no last_ret)", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("PRODUCT step + step stats ", [&] { KernelParams Q = P; Q.step_stats = 1; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, Q, io_for(step)); });
     add("PRODUCT step + last_return", [&] { StepIO io = io_for(step); io.last_return = d_last; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io); });
     add("pipe2 hist               ", [&] { hipLaunchKernelGGL((k_step_pipe<true, 2>), dim3(512), dim3(256), 0, st, P, io_for(step)); });
     add("pipe2 nohist             ", [&] { hipLaunchKernelGGL((k_step_pipe<false, 2>), dim3(512), dim3(256), 0, st, P, io_for(step)); });
