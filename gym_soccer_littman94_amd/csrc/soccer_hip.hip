@@ -320,7 +320,16 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
     const bool shared = ((P.lane_offset + P.first) & 3ull) == 0ull;
     if (explicit_u) {           // facade / test path: generic instantiations only
         if (vec && shared) launch_step3<true, true, true>(h, P, io); else launch_step3<true, false, false>(h, P, io);
-    } else if (vec && shared) launch_step3<false, true, true>(h, P, io);     // the hot instantiation
+    } else if (vec && shared) {
+        // the hot instantiations; LEAN drops the code for prob_code / final_obs / last_return / step stats
+        const bool lean = !io.prob_code && !io.final_obs && !io.last_return && !P.step_stats;
+        const int grid = grid_for(h, (P.n + 3) / 4);
+        const dim3 g(grid), b(kBlock);
+        if (lean) {
+            if (h->slip) hipLaunchKernelGGL((step_kernel<true, false, true, true, 1, kBlock, true>), g, b, 0, h->stream, P, io);
+            else hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, kBlock, true>), g, b, 0, h->stream, P, io);
+        } else launch_step3<false, true, true>(h, P, io);
+    }
     else if (vec) launch_step3<false, true, false>(h, P, io);
     else launch_step3<false, false, false>(h, P, io);
 }

@@ -218,6 +218,7 @@ int main(int argc, char** argv) {
     add("rolled E4 LDS nohist     ", [&] { hipLaunchKernelGGL((k_step_rolled<true, false>), dim3(1024), dim3(256), smem, st, P, io_for(step)); });
     add("rolled E4 global hist    ", [&] { hipLaunchKernelGGL((k_step_rolled<false, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step (no last_ret)", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("PRODUCT step LEAN         ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 256, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step + step stats ", [&] { KernelParams Q = P; Q.step_stats = 1; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, Q, io_for(step)); });
     add("PRODUCT step + last_return", [&] { StepIO io = io_for(step); io.last_return = d_last; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io); });
     add("pipe2 hist               ", [&] { hipLaunchKernelGGL((k_step_pipe<true, 2>), dim3(512), dim3(256), 0, st, P, io_for(step)); });
