@@ -180,12 +180,13 @@ class SoccerBatch:
     @staticmethod
     def mixed_policy_thresholds(probs):
         """[nS, 5] action probabilities -> uint16[nS, 4] cumulative thresholds for batched_rollout's
-        mix_a / mix_b (deterministic: floor(cumsum * 65536), clipped)."""
+        mix_a / mix_b: floor(32768 * cumulative probability), values 0..32768; the sampled action is the
+        number of thresholds <= a 15-bit draw, so deterministic rows are reproduced exactly."""
         p = np.asarray(probs, dtype=np.float64)
         assert p.ndim == 2 and p.shape[1] == 5 and (p >= 0).all() and np.allclose(p.sum(1), 1.0), \
             "probs must be [n_states, 5] rows summing to 1"
         c = np.cumsum(p, axis=1)[:, :4]
-        return np.ascontiguousarray(np.clip(np.floor(c * 65536.0), 0, 65535).astype(np.uint16))
+        return np.ascontiguousarray(np.clip(np.floor(c * 32768.0 + 1e-9), 0, 32768).astype(np.uint16))
 
     def set_policy(self, player, policy):
         """Fixed policy for 'player_a' / 'player_b' (dict or sequence: observation index -> action), or None."""

@@ -70,7 +70,7 @@ struct ResetIO {
 
 struct RolloutIO {
     int32_t n_steps; int32_t sample_actions;
-    const uint16_t* mix_a; const uint16_t* mix_b;   // [nS][4] cumulative 16-bit thresholds of a mixed policy, or nullptr
+    const uint16_t* mix_a; const uint16_t* mix_b;   // [nS][4] cumulative thresholds (0..32768) of a mixed policy, or nullptr
     const int8_t* act_a; const int8_t* act_b; long long act_stride;
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated; long long out_stride;
     int32_t* return_sum; int32_t* episode_count;
@@ -710,10 +710,10 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         for (int j = 0; j < E; ++j) {
             const Draw d = draw_from_word(words[j]);
             uint32_t a = aa.get(j), b = ab.get(j);
-            if (IO.sample_actions) {                    // two actions from one 32-bit word, 16 bits each
-                const uint32_t ha = awords[j] & 0xffffu, hb = awords[j] >> 16;
-                a = (ha * 5u) >> 16;                    // uniform
-                b = (hb * 5u) >> 16;
+            if (IO.sample_actions) {                    // two actions from one 32-bit word, 15 bits each
+                const uint32_t ha = awords[j] & 0x7fffu, hb = (awords[j] >> 16) & 0x7fffu;
+                a = (ha * 5u) >> 15;                    // uniform
+                b = (hb * 5u) >> 15;
                 if (IO.mix_a) {                         // mixed policy: first action whose cumulative threshold exceeds the draw
                     const uint2 th = *reinterpret_cast<const uint2*>(IO.mix_a + 4u * s_now[j]);
                     a = (ha >= (th.x & 0xffffu)) + (ha >= (th.x >> 16)) + (ha >= (th.y & 0xffffu)) + (ha >= (th.y >> 16));

@@ -119,8 +119,9 @@ typedef struct soccer_step_args {
 typedef struct soccer_rollout_args {
     int32_t        n_steps;     /* T >= 1 */
     int32_t        sample_actions; /* 0: read act_a/act_b; 1: draw uniform-random actions in-kernel
-                                      from the lane's word w of the purpose-1 Philox block:
-                                      a = ((w & 0xffff)*5)>>16, b = ((w >> 16)*5)>>16 */
+                                      from the lane's word w of the purpose-1 Philox block, 15 bits per
+                                      player: da = w & 0x7fff, db = (w >> 16) & 0x7fff;
+                                      a = (da*5)>>15, b = (db*5)>>15 */
     const int8_t*  act_a;       /* [T][n] (row stride act_stride) or NULL when sample_actions */
     const int8_t*  act_b;
     int64_t        act_stride;  /* elements between consecutive steps (>= n) */
@@ -131,10 +132,10 @@ typedef struct soccer_rollout_args {
     int64_t        out_stride;
     int32_t*       return_sum;  /* [n] += sum of A's rewards over the T steps, or NULL */
     int32_t*       episode_count; /* [n] += episodes finished during the T steps, or NULL */
-    /* sample_actions only: mixed (stochastic) policies, DEVICE uint16[n_states][4].  Row s holds the
-     * cumulative probabilities of actions 0..3 at observation s scaled to 0..65535 (action 4 takes the
-     * rest); the action is the number of thresholds <= the player's 16-bit draw (player A: w & 0xffff,
-     * player B: w >> 16).  NULL: uniform.  This is the self-play rollout of BASELINE config 5. */
+    /* sample_actions only: mixed (stochastic) policies, DEVICE uint16[n_states][4].  Row s holds
+     * floor(32768 * cumulative probability) of actions 0..3 at observation s (values 0..32768; action 4
+     * takes the rest); the action is the number of thresholds <= the player's 15-bit draw.  NULL:
+     * uniform.  This is the self-play rollout of BASELINE config 5. */
     const uint16_t* mix_a;
     const uint16_t* mix_b;
 } soccer_rollout_args;

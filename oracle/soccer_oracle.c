@@ -402,25 +402,26 @@ int64_t soc_oracle_batched_step(const soc_oracle* o, int64_t n, soc_state* s,
 }
 
 /* uniform-random joint action of the in-kernel sampler: the lane's word of the purpose-1 block;
- * a = ((w & 0xffff) * 5) >> 16, b = ((w >> 16) * 5) >> 16 (include/soccer_hip.h, soccer_rollout_args). */
+ * 15 bits per player: a = ((w & 0x7fff) * 5) >> 15, b = (((w >> 16) & 0x7fff) * 5) >> 15
+ * (include/soccer_hip.h, soccer_rollout_args). */
 void soc_oracle_sample_actions(int64_t n, uint64_t seed, uint64_t lane_offset, uint64_t tick,
                                int8_t* act_a, int8_t* act_b) {
     for (int64_t i = 0; i < n; ++i) {
         uint32_t w = lane_word(seed, lane_offset + (uint64_t)i, tick, 1);
-        act_a[i] = (int8_t)(((w & 0xffffu) * 5u) >> 16);
-        act_b[i] = (int8_t)(((w >> 16) * 5u) >> 16);
+        act_a[i] = (int8_t)(((w & 0x7fffu) * 5u) >> 15);
+        act_b[i] = (int8_t)((((w >> 16) & 0x7fffu) * 5u) >> 15);
     }
 }
 
-/* mixed-policy action sampling of batched_rollout (mix_a / mix_b): 16-bit draw per player from the
+/* mixed-policy action sampling of batched_rollout (mix_a / mix_b): 15-bit draw per player from the
  * lane's purpose-1 word; action = number of cumulative thresholds <= draw; NULL table = uniform. */
 void soc_oracle_sample_actions_mixed(int64_t n, uint64_t seed, uint64_t lane_offset, uint64_t tick,
                                      const uint16_t* obs_now, const uint16_t* mix_a, const uint16_t* mix_b,
                                      int8_t* act_a, int8_t* act_b) {
     for (int64_t i = 0; i < n; ++i) {
         uint32_t w = lane_word(seed, lane_offset + (uint64_t)i, tick, 1);
-        uint32_t ha = w & 0xffffu, hb = w >> 16;
-        int a = (int)((ha * 5u) >> 16), b = (int)((hb * 5u) >> 16);
+        uint32_t ha = w & 0x7fffu, hb = (w >> 16) & 0x7fffu;
+        int a = (int)((ha * 5u) >> 15), b = (int)((hb * 5u) >> 15);
         if (mix_a) { const uint16_t* t = mix_a + 4 * (size_t)obs_now[i]; a = (ha >= t[0]) + (ha >= t[1]) + (ha >= t[2]) + (ha >= t[3]); }
         if (mix_b) { const uint16_t* t = mix_b + 4 * (size_t)obs_now[i]; b = (hb >= t[0]) + (hb >= t[1]) + (hb >= t[2]) + (hb >= t[3]); }
         act_a[i] = (int8_t)a; act_b[i] = (int8_t)b;

@@ -1,0 +1,92 @@
+"""CPU tests of the host-side logic that needs no device: spaces stand-ins, registration table,
+mixed-policy threshold conversion, the C oracle's action samplers, and the closed-form state numbering
+against the reference's tables."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import gym_soccer_littman94_amd as gsa
+from gym_soccer_littman94_amd import spaces
+from gym_soccer_littman94_amd.core import SoccerBatch
+from gym_soccer_littman94_amd.registration import ENV_SPECS
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_spaces_behave_like_gym_spaces():
+    d = spaces.Dict({'player_a': spaces.Discrete(761), 'player_b': spaces.Discrete(5)})
+    assert d['player_a'].n == 761 and 'player_b' in d and len(d) == 2
+    x = d.sample()
+    assert set(x) == {'player_a', 'player_b'} and 0 <= x['player_a'] < 761 and d.contains(x)
+    assert not d.contains({'player_a': 761, 'player_b': 0}) and not d.contains({'player_a': 0})
+    m = spaces.MultiDiscrete(np.full(16, 5))
+    s = m.sample()
+    assert s.shape == (16,) and m.contains(s) and not m.contains(s + 5)
+
+
+def test_registration_table_matches_the_reference_stub():
+    # gym_soccer/__init__.py:5-12 (commented out there): id, entry point class, kwargs
+    spec = ENV_SPECS["SoccerSimultaneous-v0"]
+    assert spec["entry_point"].endswith(":SoccerSimultaneousEnv")
+    assert spec["kwargs"] == {"width": 5, "height": 4, "slip_prob": 0.2, "player_a_policy": None, "player_b_policy": None}
+    assert ENV_SPECS["SoccerLittman94-v0"]["kwargs"]["slip_prob"] == 0.0
+    with pytest.raises(KeyError):
+        gsa.make("NoSuchEnv-v0")
+    assert isinstance(gsa.register_all(), list)
+
+
+def test_mixed_policy_thresholds_are_exact_and_monotone():
+    rng = np.random.default_rng(0)
+    p = rng.dirichlet(np.ones(5), size=761)
+    t = SoccerBatch.mixed_policy_thresholds(p)
+    assert t.dtype == np.uint16 and t.shape == (761, 4) and (np.diff(t.astype(int), axis=1) >= 0).all()
+    # a deterministic policy maps to thresholds that select exactly that action for every 15-bit draw
+    det = np.eye(5)[rng.integers(0, 5, size=761)]
+    td = SoccerBatch.mixed_policy_thresholds(det).astype(np.int64)
+    for draw in (0, 1, 16384, 32767):
+        np.testing.assert_array_equal((draw >= td).sum(1), det.argmax(1))
+    with pytest.raises(AssertionError):
+        SoccerBatch.mixed_policy_thresholds(np.ones((761, 5)))
+    # empirical frequencies of the sampler follow the table
+    probs = np.array([[0.1, 0.2, 0.3, 0.15, 0.25]])
+    th = SoccerBatch.mixed_policy_thresholds(probs).astype(np.int64)[0]
+    draws = np.arange(32768)
+    freq = np.bincount((draws[:, None] >= th[None, :]).sum(1), minlength=5) / 32768
+    np.testing.assert_allclose(freq, probs[0], atol=4e-5)
+
+
+def test_oracle_action_samplers_are_uniform_and_lane_stable():
+    from oracle.oracle import Oracle
+    o = Oracle(5, 4, 0.0, n=200000, seed=3, lane_offset=8)
+    a, b = o.sample_actions(tick=5)
+    for x in (a, b):
+        f = np.bincount(x, minlength=5) / x.size
+        assert x.min() >= 0 and x.max() <= 4 and np.abs(f - 0.2).max() < 0.01
+    # lane g's draw depends on the global lane id only, not on where the shard starts
+    o2 = Oracle(5, 4, 0.0, n=1000, seed=3, lane_offset=8 + 777)
+    a2, b2 = o2.sample_actions(tick=5)
+    np.testing.assert_array_equal(a2, a[777:1777]); np.testing.assert_array_equal(b2, b[777:1777])
+    a3, _ = o.sample_actions(tick=6)
+    assert (a3 != a).mean() > 0.7
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "table_*_s0.npz"))))
+def test_closed_form_state_numbering_matches_reference_tables(path):
+    """obs = 1 + 2*(iA*(NI-1) + iB - (iB > iA)) + p over interior-cell indices (csrc/soccer_rules.hpp
+    self-checks its table against the same formula at create time)."""
+    g = np.load(path)
+    W = int(g["width"]) + 2; H = int(g["height"]); NI = H * (W - 2)
+    lut = g["lut"]; kind = g["kind"]
+    assert int(g["nS"]) == NI * (NI - 1) * 2 + 1
+    idx = np.arange(lut.size)
+    p = idx & 1; r = idx >> 1
+    yb = r % W; r //= W; xb = r % H; r //= H; ya = r % W; xa = r // W
+    live = kind == 1
+    ia = xa * (W - 2) + ya - 1; ib = xb * (W - 2) + yb - 1
+    want = 1 + 2 * (ia * (NI - 1) + ib - (ib > ia)) + p
+    np.testing.assert_array_equal(lut[live], want[live])
+    interior = (ya > 0) & (ya < W - 1) & (yb > 0) & (yb < W - 1) & ~((xa == xb) & (ya == yb))
+    np.testing.assert_array_equal(live, interior)
+    assert (lut[kind == 2] == 0).all() and (lut[kind == 0] == 0xFFFF).all()

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void k_step_pipe(const KernelParams P, const S
 
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; };
 #include <functional>
+#include <chrono>
 
 int main(int argc, char** argv) {
     const size_t N = 1 << 20;
@@ -232,6 +233,15 @@ int main(int argc, char** argv) {
     add("PRODUCT step  256 x 1024  ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 1024>), dim3(256), dim3(1024), 0, st, P, io_for(step)); });
     add("PRODUCT step bytes (VEC=0)", [&] { hipLaunchKernelGGL((step_kernel<false, false, false, false>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("rolled E4 global nohist  ", [&] { hipLaunchKernelGGL((k_step_rolled<false, false>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    // two (or four) independent lane ranges on separate streams: phases of different ranges can overlap
+    hipStream_t st2[4]; for (auto& x : st2) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    auto split_launch = [&](int parts, int k) {
+        for (int q = 0; q < parts; ++q) {
+            KernelParams Q = P; Q.first = (unsigned long long)q * (N / parts); Q.n = N / parts;
+            if (q) Q.tick_out = nullptr;
+            hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 256, true>), dim3(1024 / parts), dim3(256), 0, st2[q], Q, io_for(k));
+        }
+    };
     // reset state so `step` variants act on valid tuples: run the real reset first
     { ResetIO rio{nullptr, nullptr, nullptr}; hipLaunchKernelGGL(reset_kernel<true>, dim3(1024), dim3(256), smem, st, P, rio); CK(hipStreamSynchronize(st)); }
     for (int r = 0; r < ROUNDS; ++r) for (auto& v : V) {
@@ -242,6 +252,33 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); v.ms.push_back(ms * 1000.f / K);
         CK(hipGetLastError());
+    }
+    for (int parts : {2, 4}) {
+        std::vector<float> ms;
+        for (int r = 0; r < ROUNDS; ++r) {
+            for (int k = 0; k < 10; ++k) split_launch(parts, k);
+            for (int q = 0; q < parts; ++q) CK(hipStreamSynchronize(st2[q]));
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int k = 0; k < K; ++k) split_launch(parts, k);
+            for (int q = 0; q < parts; ++q) CK(hipStreamSynchronize(st2[q]));
+            auto t1 = std::chrono::high_resolution_clock::now();
+            ms.push_back(std::chrono::duration<float, std::micro>(t1 - t0).count() / K);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("split in %d ranges on %d streams (host wall): median %.2f min %.2f us per full step\n", parts, parts, ms[ms.size() / 2], ms[0]);
+    }
+    {   // same measurement method for the single-stream kernel, for comparison
+        std::vector<float> ms;
+        for (int r = 0; r < ROUNDS; ++r) {
+            CK(hipStreamSynchronize(st));
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int k = 0; k < K; ++k) hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 256, true>), dim3(1024), dim3(256), 0, st, P, io_for(k));
+            CK(hipStreamSynchronize(st));
+            auto t1 = std::chrono::high_resolution_clock::now();
+            ms.push_back(std::chrono::duration<float, std::micro>(t1 - t0).count() / K);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("single stream LEAN (host wall): median %.2f min %.2f us per full step\n", ms[ms.size() / 2], ms[0]);
     }
     printf("%-28s %8s %8s   (us per launch, N=2^20, %d launches x %d rounds)\n", "variant", "median", "min", K, ROUNDS);
     for (auto& v : V) { std::sort(v.ms.begin(), v.ms.end()); printf("%-28s %8.2f %8.2f\n", v.name.c_str(), v.ms[v.ms.size() / 2], v.ms[0]); }
