@@ -369,6 +369,50 @@ def test_results_do_not_depend_on_sharding_or_vector_width():
     np.testing.assert_array_equal(hf, ha + hc)
 
 
+def test_config4_full_size_eight_shards_equal_one_handle_and_invariants():
+    """BASELINE config 4 at full size on one GPU: 8 388 608 lanes as ONE handle vs 8 shards of 2^20 with
+    global lane offsets (what 8 GPUs would each own) — identical per-lane results — plus the
+    size-independent invariants of the outputs."""
+    n, G, T = 1 << 23, 8, 30
+    per = n // G
+    big = SoccerBatch(n, 5, 4, 0.0, seed=2024, autoreset=True)
+    big.reset()
+    rs = big.alloc(n, np.int32).fill(0); ec = big.alloc(n, np.int32).fill(0)
+    obs = big.alloc((T, n), np.uint16); rew = big.alloc((T, n), np.int8)
+    term = big.alloc((T, n), np.uint8); trunc = big.alloc((T, n), np.uint8)
+    big.rollout(T, sample_actions=True, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
+                return_sum=rs, episode_count=ec)
+    R_big, E_big, S_big = rs.download(), ec.download(), big.get_state()
+    O, RW, TE, TR = obs.download(), rew.download(), term.download(), trunc.download()
+    hist_big = big.stats()[0]
+    del obs, rew, term, trunc
+    big.close()
+    hist_sum = np.zeros(3, np.uint64)
+    for g in range(G):
+        b = SoccerBatch(per, 5, 4, 0.0, seed=2024, autoreset=True, lane_offset=g * per)
+        b.reset()
+        r = b.alloc(per, np.int32).fill(0); e = b.alloc(per, np.int32).fill(0)
+        b.rollout(T, sample_actions=True, return_sum=r, episode_count=e)
+        sl = slice(g * per, (g + 1) * per)
+        np.testing.assert_array_equal(r.download(), R_big[sl]); np.testing.assert_array_equal(e.download(), E_big[sl])
+        s = b.get_state()
+        for k in ("row_a", "col_a", "row_b", "col_b", "poss", "t"):
+            np.testing.assert_array_equal(s[k], S_big[k][sl], err_msg=k)
+        hist_sum += b.stats()[0]
+        b.close()
+    np.testing.assert_array_equal(hist_sum, hist_big)
+    # invariants of the step outputs at full size
+    fin = (TE | TR).astype(bool)
+    assert int(fin.sum()) == int(hist_big.sum()) == int(E_big.sum())
+    assert ((RW != 0) <= (TE == 1)).all()                      # a reward only on the scoring step
+    assert int((RW == 1).sum()) == int(hist_big[2]) and int((RW == -1).sum()) == int(hist_big[0])
+    assert not TR.any()                                        # 30 steps < 100: nothing truncates
+    assert np.isin(O[fin], (253, 254, 435, 436)).all()         # auto-reset: a fresh episode's first observation
+    assert (O > 0).all() and (O < 761).all()
+    assert int(R_big.sum()) == int(RW.astype(np.int64).sum())
+    np.testing.assert_array_equal(S_big["t"] <= T, True)
+
+
 def test_graph_capture_replays_advance_the_tick():
     n, T = 8192, 6
     rng = np.random.default_rng(3)
