@@ -211,6 +211,17 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
         volatile double c2a = s * one_minus;  volatile double c2 = c2a * 0.5;
         volatile double c3a = s * s;          volatile double c3 = c3a * 0.25;
         P.w[0] = c0; P.w[1] = c1; P.w[2] = c2; P.w[3] = c3;
+        // nominal thresholds of the slip fast path: running sum of the active weights in list order
+        static const int cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+        volatile double acc = 0.0;
+        P.nb = 0; P.act_pack = 0;
+        for (int c = 0; c < 9; ++c) P.B[c] = __builtin_inf();
+        for (int c = 0; c < 9; ++c) {
+            const double wc = P.w[cls[c]];
+            if (wc == 0.0) continue;
+            acc = acc + wc;
+            P.B[P.nb] = acc; P.act_pack |= (unsigned long long)c << (4 * P.nb); ++P.nb;
+        }
     }
     set_key(h, cfg->seed);
     h->slip = cfg->slip_prob != 0.0;

@@ -55,6 +55,9 @@ struct KernelParams {
     uint32_t step_stats;                  // batched_step feeds the episode histogram (SOCCER_F_STEP_STATS)
     uint32_t isd_shift;                   // 2 - log2(n_isd): index = two random bits >> isd_shift
     double w[4];                          // slip-combination weights c0..c3 (:211-222)
+    // slip fast path: cumulative weight after each ACTIVE (non-zero) combination in reference order
+    // (+inf beyond), their count, and their combination ids packed 4 bits each
+    double B[9]; uint32_t nb; unsigned long long act_pack;
 };
 
 struct StepIO {
@@ -249,32 +252,68 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
             cellA[v] = moved(T, P, A, p ^ 1u, slip_move(aa, v));
             cellB[v] = moved(T, P, B, p, slip_move(ab, v));
         }
-        // Walk the list exactly as categorical_sample does — sequential float64 running sum over the
-        // combinations in reference order, each contributing 1, 2 or 4 equal entries — but only record
-        // WHICH entry (combination c, outcome k) is the first to exceed u; the outcome itself is built
-        // once, after the loop.
-        double acc = 0.0;
-        bool found = false;
-        uint32_t sel_c = 0u, sel_k = 0u;
-        int first_c = -1;                                               // wave-uniform (weights are)
+        // (1) Fast decision.  The list's running sums are, up to rounding, the cumulative weights of the
+        // active combinations (P.B, summed on the host in the reference's order) plus multiples of the
+        // combination's own q; the true float64 sums differ from these nominal values by < 1e-14 (at most
+        // 36 additions of terms <= 1).  If u is farther than 2^-40 from every nominal threshold it can be
+        // compared against, the entry found from the nominal thresholds IS the entry the sequential sum
+        // finds.  Otherwise (u on or next to a threshold, or beyond the last one) the lane takes the exact
+        // path (2).
+        uint32_t idx = 0u; bool near_thr = false; double S = 0.0;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const double wgt = P.w[CLS[c]];
-            if (wgt == 0.0) continue;                                   // uniform branch (:226-227)
-            if (first_c < 0) first_c = c;
-            const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cellA[VA[c]], cellB[VB[c]], aa, ab).kind;
-            const uint32_t n = kind == K_COIN ? 2u : (kind == K_FOUR ? 4u : 1u);
-            const double q = wgt * (n == 1u ? 1.0 : (n == 2u ? 0.5 : 0.25));   // :241
-            const double a1 = acc + q, a2 = a1 + q, a3 = a2 + q, a4 = a3 + q;   // sequential cumsum
-            const double end = n == 1u ? a1 : (n == 2u ? a2 : a4);
-            const uint32_t k = (d.u >= a1 ? 1u : 0u) + (((n > 1u) & (d.u >= a2)) ? 1u : 0u) +
-                               (((n > 2u) & (d.u >= a3)) ? 1u : 0u);
-            const bool here = !found & (end > d.u);
-            sel_c = here ? (uint32_t)c : sel_c; sel_k = here ? k : sel_k;
-            found |= here;
-            acc = end;
+        for (int i = 0; i < 9; ++i) {
+            const double b = P.B[i];                                    // wave-uniform; +inf past the last active one
+            const bool ge = d.u >= b;
+            idx += ge ? 1u : 0u;
+            S = ge ? b : S;
+            near_thr |= fabs(d.u - b) < 0x1.0p-40;
         }
-        if (!found) { sel_c = (uint32_t)(first_c < 0 ? 0 : first_c); sel_k = 0u; }   // argmax of all-False is 0
+        near_thr |= idx >= P.nb;
+        uint32_t sel_c = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull), sel_k = 0u;
+        {
+            constexpr uint32_t VA2f = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
+            constexpr uint32_t VB2f = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
+            constexpr uint32_t CL2f = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
+            const uint32_t va = (VA2f >> (2u * sel_c)) & 3u, vb = (VB2f >> (2u * sel_c)) & 3u, cl = (CL2f >> (2u * sel_c)) & 3u;
+            const uint32_t cA = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
+            const uint32_t cB = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
+            const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cA, cB, aa, ab).kind;
+            const uint32_t n = kind == K_COIN ? 2u : (kind == K_FOUR ? 4u : 1u);
+            const double wq = cl & 2u ? (cl & 1u ? P.w[3] : P.w[2]) : (cl & 1u ? P.w[1] : P.w[0]);
+            const double q = wq * (n == 1u ? 1.0 : (n == 2u ? 0.5 : 0.25));
+            const double t1 = S + q, t2 = t1 + q, t3 = t2 + q;
+            sel_k = (((n > 1u) & (d.u >= t1)) ? 1u : 0u) + (((n > 2u) & (d.u >= t2)) ? 1u : 0u) +
+                    (((n > 2u) & (d.u >= t3)) ? 1u : 0u);
+            near_thr |= (n > 1u) & (fabs(d.u - t1) < 0x1.0p-40);
+            near_thr |= (n > 2u) & (fabs(d.u - t2) < 0x1.0p-40);
+            near_thr |= (n > 2u) & (fabs(d.u - t3) < 0x1.0p-40);
+        }
+        // (2) Exact decision, exactly as categorical_sample walks the list: sequential float64 running sum
+        // over the combinations in reference order, each contributing 1, 2 or 4 equal entries; record
+        // WHICH entry (combination c, outcome k) is the first to exceed u.
+        if (near_thr) {
+            double acc = 0.0;
+            bool found = false;
+            int first_c = -1;                                           // wave-uniform (weights are)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const double wgt = P.w[CLS[c]];
+                if (wgt == 0.0) continue;                               // uniform branch (:226-227)
+                if (first_c < 0) first_c = c;
+                const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cellA[VA[c]], cellB[VB[c]], aa, ab).kind;
+                const uint32_t n = kind == K_COIN ? 2u : (kind == K_FOUR ? 4u : 1u);
+                const double q = wgt * (n == 1u ? 1.0 : (n == 2u ? 0.5 : 0.25));   // :241
+                const double a1 = acc + q, a2 = a1 + q, a3 = a2 + q, a4 = a3 + q;   // sequential cumsum
+                const double end = n == 1u ? a1 : (n == 2u ? a2 : a4);
+                const uint32_t k = (d.u >= a1 ? 1u : 0u) + (((n > 1u) & (d.u >= a2)) ? 1u : 0u) +
+                                   (((n > 2u) & (d.u >= a3)) ? 1u : 0u);
+                const bool here = !found & (end > d.u);
+                sel_c = here ? (uint32_t)c : sel_c; sel_k = here ? k : sel_k;
+                found |= here;
+                acc = end;
+            }
+            if (!found) { sel_c = (uint32_t)(first_c < 0 ? 0 : first_c); sel_k = 0u; }   // argmax of all-False is 0
+        }
         // VA / VB / CLS of the selected combination, 2 bits each
         constexpr uint32_t VA2 = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
         constexpr uint32_t VB2 = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);

@@ -192,7 +192,7 @@ int main(int argc, char** argv) {
     P.tick_in = d_tick; P.tick_out = d_tick + 16; P.key0 = 1; P.key1 = 2; P.lane_offset = 0;
     P.hist = d_hist; P.misuse = d_mis; P.first = 0; P.n = N; P.W = R.W; P.HW = R.H * R.W; P.HW5 = 5 * R.H * R.W;
     P.nc_len = (int)R.next_cell.size(); P.max_steps = 100; P.autoreset = 1; P.step_stats = 0; P.isd_shift = 0;
-    P.w[0] = 1; P.w[1] = P.w[2] = P.w[3] = 0;
+    P.w[0] = 1; P.w[1] = P.w[2] = P.w[3] = 0; P.nb = 1; P.act_pack = 0; for (int c = 0; c < 9; ++c) P.B[c] = c ? __builtin_inf() : 1.0;
     const size_t smem = (kIsdWords + R.next_cell.size()) * 4 + R.lut.size() * 2;
     // actions: T rows cycled
     const int T = 64;
