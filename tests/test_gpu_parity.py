@@ -200,6 +200,43 @@ def test_config2_autoreset_every_lane_every_step_vs_oracle(slip, width, height, 
     b.close()
 
 
+@pytest.mark.parametrize("slip,width,height", [(0.2, 5, 4), (0.5, 5, 4), (1.0, 5, 4), (0.3, 7, 5), (0.25, 5, 4)])
+def test_slip_thresholds_hit_exactly_and_within_rounding_distance(slip, width, height):
+    """The slip kernel decides most draws from nominal thresholds and walks the exact float64 running
+    sum only when u is within 2^-40 of one.  Probe both sides of that switch: uniforms exactly on,
+    one ulp / 1e-15 / 1e-13 / 2e-12 / 1e-9 around every threshold of real transition lists."""
+    o_tab = Oracle(width, height, slip, n=1)
+    lut, kind, *_ = o_tab.tables()
+    W = width + 2
+    rng = np.random.default_rng(17)
+    live = np.flatnonzero(kind == 1)
+    states, acts, us = [], [], []
+    deltas = [0.0, 1e-15, -1e-15, 1e-13, -1e-13, 2e-12, -2e-12, 1e-9, -1e-9]
+    for f in rng.choice(live, 260, replace=False):
+        p_ = f & 1; r = f >> 1; yb = r % W; r //= W; xb = r % height; r //= height; ya = r % W; xa = r // W
+        aa, ab = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        probs, *_ = o_tab.transitions([xa, ya, xb, yb, p_], aa, ab)
+        for thr in np.cumsum(probs):
+            for d in deltas:
+                for u in (thr + d, np.nextafter(thr, 0.0) if d == 0.0 else None, np.nextafter(thr, 2.0) if d == 0.0 else None):
+                    if u is None or not (0.0 <= u < 1.0):
+                        continue
+                    states.append((xa, ya, xb, yb, p_)); acts.append((aa, ab)); us.append(u)
+    st = np.array(states, np.int8); ac = np.array(acts, np.int8); u = np.array(us, np.float64)
+    n = len(u)
+    assert n > 5000
+    b = SoccerBatch(n, width, height, slip)
+    o = Oracle(width, height, slip, n=n)
+    for x in (b, o):
+        x.set_state(st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], t=0, needs_reset=np.zeros(n, np.uint8))
+    got = b.step_host(ac[:, 0], ac[:, 1], u_step=u)
+    want = o.step(ac[:, 0], ac[:, 1], u_step=u)
+    for k in ("obs", "reward", "terminated", "truncated", "prob_code"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    assert_state_equal(b, o)
+    b.close()
+
+
 @pytest.mark.parametrize("learner", ["player_a", "player_b"])
 def test_single_agent_tables_every_row(learner):
     """Fixed-opponent mode against the REFERENCE's single-agent transition table (all ~43 000 rows):
