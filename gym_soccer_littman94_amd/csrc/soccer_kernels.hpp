@@ -633,10 +633,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
                 if (IO.u_step) { const double u = sane_uniform(IO.u_step[i0 + j]); d.u = u; d.top2 = (uint32_t)(u * 4.0); }
                 if (IO.u_reset) d.reset2 = (uint32_t)(sane_uniform(IO.u_reset[i0 + j]) * 4.0);
             }
+            // byte j of every packed stream: one v_bfe_u32 each (the offset 8*j is wave-uniform)
+            const uint32_t sh = 8u * (uint32_t)j;
+            const uint32_t psj = __builtin_amdgcn_ubfe(ps, sh, 8u);
             Lane L;
-            L.A = make_pos(ra & 0xffu, ca & 0xffu, P.W); L.B = make_pos(rb & 0xffu, cb & 0xffu, P.W);
-            L.p = ps & 1u; L.need = (ps >> 1) & 1u; L.t = tt & 0xffu;
-            uint32_t a_now = aa & 0xffu, b_now = ab & 0xffu;
+            L.A = make_pos(__builtin_amdgcn_ubfe(ra, sh, 8u), __builtin_amdgcn_ubfe(ca, sh, 8u), P.W);
+            L.B = make_pos(__builtin_amdgcn_ubfe(rb, sh, 8u), __builtin_amdgcn_ubfe(cb, sh, 8u), P.W);
+            L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
+            uint32_t a_now = __builtin_amdgcn_ubfe(aa, sh, 8u), b_now = __builtin_amdgcn_ubfe(ab, sh, 8u);
             if (EXPLICIT_U && (P.policy_a || P.policy_b)) {         // the fixed side acts on the current observation
                 const uint32_t s_now = obs_of(T, P, L.A, L.B, L.p);
                 if (P.policy_a) a_now = (uint32_t)(uint8_t)P.policy_a[s_now];
@@ -644,7 +648,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
             }
             StepResult R;
             mis |= lane_step<SLIP>(T, P, L, a_now, b_now, d, R);
-            ra >>= 8; ca >>= 8; rb >>= 8; cb >>= 8; ps >>= 8; tt >>= 8; aa >>= 8; ab >>= 8;
             nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
             nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
             nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
