@@ -267,6 +267,39 @@ int main(int argc, char** argv) {
         std::sort(ms.begin(), ms.end());
         printf("split in %d ranges on %d streams (host wall): median %.2f min %.2f us per full step\n", parts, parts, ms[ms.size() / 2], ms[0]);
     }
+    // graph with a fork/join per step: the step's lane ranges run as parallel branches
+    for (int parts : {1, 2, 4}) {
+        hipGraph_t graph; hipGraphExec_t exec;
+        hipEvent_t fork, join[4]; CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (auto& e : join) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < K; ++k) {
+            if (parts == 1) {
+                hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 256, true>), dim3(1024), dim3(256), 0, st, P, io_for(k));
+                continue;
+            }
+            CK(hipEventRecord(fork, st));
+            for (int q = 0; q < parts; ++q) {
+                hipStream_t s2 = q == 0 ? st : st2[q];
+                if (q) CK(hipStreamWaitEvent(s2, fork, 0));
+                KernelParams Q = P; Q.first = (unsigned long long)q * (N / parts); Q.n = N / parts;
+                if (q) Q.tick_out = nullptr;
+                hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 256, true>), dim3(1024 / parts), dim3(256), 0, s2, Q, io_for(k));
+                if (q) { CK(hipEventRecord(join[q], s2)); CK(hipStreamWaitEvent(st, join[q], 0)); }
+            }
+        }
+        CK(hipStreamEndCapture(st, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        std::vector<float> ms;
+        for (int r = 0; r < ROUNDS; ++r) {
+            CK(hipGraphLaunch(exec, st)); CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(exec, st)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t * 1000.f / K);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("graph, %d parallel lane range(s) per step: median %.2f min %.2f us per full step\n", parts, ms[ms.size() / 2], ms[0]);
+        CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+    }
     {   // same measurement method for the single-stream kernel, for comparison
         std::vector<float> ms;
         for (int r = 0; r < ROUNDS; ++r) {
