@@ -111,7 +111,10 @@ static void set_key(soccer_handle* h, uint64_t seed) {
 
 template <int E, bool SLIP, bool LUT_LDS>
 static hipError_t raise_smem_limit(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<E, SLIP, LUT_LDS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<E, SLIP, LUT_LDS, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<E, SLIP, LUT_LDS, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
@@ -381,17 +384,23 @@ extern "C" int batched_step(soccer_handle* h, const int8_t* act_a, const int8_t*
     return batched_step_ex(h, &a);
 }
 
-template <int E>
-static void launch_rollout(soccer_handle* h, const KernelParams& P, const RolloutIO& io) {
+template <int E, bool DYN>
+static void launch_rollout2(soccer_handle* h, const KernelParams& P, const RolloutIO& io) {
     const int grid = grid_for(h, (P.n + E - 1) / E);
     const dim3 g(grid), b(kBlock);
     if (h->slip) {
-        if (h->lut_lds) hipLaunchKernelGGL((rollout_kernel<E, true, true>), g, b, h->smem_bytes, h->stream, P, io);
-        else hipLaunchKernelGGL((rollout_kernel<E, true, false>), g, b, h->smem_bytes, h->stream, P, io);
+        if (h->lut_lds) hipLaunchKernelGGL((rollout_kernel<E, true, true, DYN>), g, b, h->smem_bytes, h->stream, P, io);
+        else hipLaunchKernelGGL((rollout_kernel<E, true, false, DYN>), g, b, h->smem_bytes, h->stream, P, io);
     } else {
-        if (h->lut_lds) hipLaunchKernelGGL((rollout_kernel<E, false, true>), g, b, h->smem_bytes, h->stream, P, io);
-        else hipLaunchKernelGGL((rollout_kernel<E, false, false>), g, b, h->smem_bytes, h->stream, P, io);
+        if (h->lut_lds) hipLaunchKernelGGL((rollout_kernel<E, false, true, DYN>), g, b, h->smem_bytes, h->stream, P, io);
+        else hipLaunchKernelGGL((rollout_kernel<E, false, false, DYN>), g, b, h->smem_bytes, h->stream, P, io);
     }
+}
+template <int E>
+static void launch_rollout(soccer_handle* h, const KernelParams& P, const RolloutIO& io) {
+    // DYN: some action is produced in the kernel (sampling, mixed policy, fixed policy)
+    const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
+    if (dyn) launch_rollout2<E, true>(h, P, io); else launch_rollout2<E, false>(h, P, io);
 }
 
 extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {

@@ -717,7 +717,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KernelParams P, con
 // =================================================================================================
 // batched_rollout: T fused steps, state in registers, actions streamed in, trajectories streamed out
 // =================================================================================================
-template <int E, bool SLIP>
+// DYN = false: both action streams come from memory (the trajectory collector); the code for in-kernel
+// sampling, mixed policies and the fixed-policy gather is compiled out.
+template <int E, bool SLIP, bool DYN>
 __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParams& P, const RolloutIO& IO,
                                               unsigned long long i0, unsigned long long tick0,
                                               HistAcc<false>& hist, bool& any_misuse) {
@@ -726,33 +728,34 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
 #pragma unroll
     for (int j = 0; j < E; ++j) { ret[j] = 0; eps[j] = 0; }
     PackB<E> aa, ab; aa.clear(); ab.clear();
-    if (!IO.sample_actions) {
-        if (IO.act_a) aa.load(IO.act_a, i0);
-        if (IO.act_b) ab.load(IO.act_b, i0);
+    const bool sample = DYN && IO.sample_actions;
+    if (!sample) {
+        if (!DYN || IO.act_a) aa.load(IO.act_a, i0);
+        if (!DYN || IO.act_b) ab.load(IO.act_b, i0);
     }
     // the observation of the current tuple is carried along when an action depends on it
-    const bool fixed = P.policy_a != nullptr || P.policy_b != nullptr ||    // single-agent mode
-                       (IO.sample_actions && (IO.mix_a != nullptr || IO.mix_b != nullptr));
+    const bool fixed = DYN && (P.policy_a != nullptr || P.policy_b != nullptr ||    // single-agent mode
+                               (sample && (IO.mix_a != nullptr || IO.mix_b != nullptr)));
     uint32_t s_now[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) s_now[j] = fixed ? obs_of(T, P, S.L[j].A, S.L[j].B, S.L[j].p) : 0u;
     for (int s = 0; s < IO.n_steps; ++s) {
         const unsigned long long tick = tick0 + (unsigned long long)s;
         PackB<E> naa = aa, nab = ab;
-        if (!IO.sample_actions && s + 1 < IO.n_steps) {                 // prefetch the next step's actions
-            if (IO.act_a) naa.load(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
-            if (IO.act_b) nab.load(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
+        if (!sample && s + 1 < IO.n_steps) {                            // prefetch the next step's actions
+            if (!DYN || IO.act_a) naa.load(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
+            if (!DYN || IO.act_b) nab.load(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
         }
         uint32_t words[E], awords[E];
         lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
-        if (IO.sample_actions) lane_words<E>(P, P.lane_offset + i0, tick, 1u, awords);
+        if (sample) lane_words<E>(P, P.lane_offset + i0, tick, 1u, awords);
         PackB<E> o_rew, o_term, o_trunc; PackH<E> o_obs;
         o_rew.clear(); o_term.clear(); o_trunc.clear(); o_obs.clear();
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const Draw d = draw_from_word(words[j]);
             uint32_t a = aa.get(j), b = ab.get(j);
-            if (IO.sample_actions) {                    // two actions from one 32-bit word, 15 bits each
+            if (sample) {                               // two actions from one 32-bit word, 15 bits each
                 const uint32_t ha = awords[j] & 0x7fffu, hb = (awords[j] >> 16) & 0x7fffu;
                 a = (ha * 5u) >> 15;                    // uniform
                 b = (hb * 5u) >> 15;
@@ -771,7 +774,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
             }
             StepResult R;
             any_misuse |= lane_step<SLIP>(T, P, S.L[j], a, b, d, R);
-            s_now[j] = R.obs;
+            if (DYN) s_now[j] = R.obs;
             o_obs.put(j, R.obs); o_rew.put(j, (uint32_t)R.reward & 0xffu); o_term.put(j, R.term); o_trunc.put(j, R.trunc);
             ret[j] += R.reward; eps[j] += (int32_t)R.finished;
             hist.add(R.finished, R.reward);
@@ -788,7 +791,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
     if (IO.episode_count) add_words<E>(IO.episode_count, i0, eps);
 }
 
-template <int E, bool SLIP, bool LUT_LDS>
+template <int E, bool SLIP, bool LUT_LDS, bool DYN>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const KernelParams P, const RolloutIO IO) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     HistAcc<false> hist; hist.init(P);
@@ -801,10 +804,10 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const KernelParams P, c
          g += (unsigned long long)gridDim.x * kBlock) {
         const unsigned long long i0 = g * E;
         if (E == 1 || i0 + E <= P.n) {
-            rollout_group<E, SLIP>(T, P, IO, i0, tick0, hist, any_misuse);
+            rollout_group<E, SLIP, DYN>(T, P, IO, i0, tick0, hist, any_misuse);
         } else {
             for (unsigned long long i = i0; i < P.n; ++i)
-                rollout_group<1, SLIP>(T, P, IO, i, tick0, hist, any_misuse);
+                rollout_group<1, SLIP, DYN>(T, P, IO, i, tick0, hist, any_misuse);
         }
     }
     if (any_misuse) *P.misuse = 1u;
