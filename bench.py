@@ -94,7 +94,8 @@ def main():
     N, K, W = args.lanes, args.steps, args.warmup
     lane_lo, lane_hi = shard_range(world * N, rank, world)      # contiguous global lane ids of this rank
     assert lane_hi - lane_lo == N
-    K += K % 2                                   # a captured sequence holds an even number of launches
+    KG = K - (K % 2)                             # a captured sequence holds an even number of launches;
+                                                 # an odd K adds one eager launch inside the timed region
     b = SoccerBatch(N, 5, 4, args.slip, seed=0, autoreset=True, device=local_rank,
                     lane_offset=lane_lo, envs_per_thread=args.envs_per_thread, step_stats=False)
 
@@ -117,9 +118,9 @@ def main():
         enqueue(k % K)
     b.sync()
     graph = None
-    if args.mode == "graph":
+    if args.mode == "graph" and KG > 0:
         b.graph_begin()
-        for k in range(K):
+        for k in range(KG):
             enqueue(k)
         graph = b.graph_end()
     b.reset_stats()
@@ -134,6 +135,8 @@ def main():
     b.timer_start()
     if graph is not None:
         b.graph_launch(graph, 1)
+        for k in range(KG, K):
+            enqueue(k)
     else:
         for k in range(K):
             enqueue(k)
@@ -163,8 +166,10 @@ def main():
         gathered = last_ret
     # cheap end-to-end sanity on the real outputs of the timed steps (not a parity test)
     n_fin = int(fin.sum()); r_sum = int(rew.to(torch.int32).sum())
-    assert 0 < n_fin < K * N and abs(r_sum) < n_fin and int(hist.sum()) == n_fin, "implausible outputs"
-    assert int(obs.max()) < b.nS and int(rew.abs().max()) == 1
+    assert n_fin < K * N and abs(r_sum) <= n_fin and int(hist.sum()) == n_fin, "implausible outputs"
+    assert int(obs.max()) < b.nS and int(rew.abs().max()) <= 1
+    if K >= 50:                     # long enough for goals to have been scored
+        assert n_fin > 0 and int(rew.abs().max()) == 1, "implausible outputs"
     del fin
 
     # ---- optional: fused T-step rollout (state in registers, same per-step results) -------------
