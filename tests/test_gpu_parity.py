@@ -291,6 +291,29 @@ def test_single_agent_rollout_and_step_agree_with_oracle_policy_gather():
     b.close(); b2.close()
 
 
+@pytest.mark.parametrize("slip,n,off", [(0.0, 65536, 0), (0.0, 65536 + 6, 1 << 33), (0.2, 32768, 4 * 123457), (0.0, 5, 0), (0.2, 3, 8)])
+def test_hot_instantiation_plain_step_vs_oracle(slip, n, off):
+    """The instantiation bench.py times: lane offset a multiple of 4 (one Philox block per thread), dword
+    I/O, only the four mandatory outputs (LEAN), no step statistics — every lane, every step."""
+    steps = 130
+    rng = np.random.default_rng(77)
+    b = SoccerBatch(n, 5, 4, slip, seed=9, autoreset=True, lane_offset=off, step_stats=False)
+    o = Oracle(5, 4, slip, n=n, seed=9, lane_offset=off, autoreset=True)
+    b.reset(); o.reset()
+    aa = b.alloc(n, np.int8); ab = b.alloc(n, np.int8)
+    obs = b.alloc(n, np.uint16); rew = b.alloc(n, np.int8); term = b.alloc(n, np.uint8); trunc = b.alloc(n, np.uint8)
+    for k in range(steps):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        aa.upload(a[0]); ab.upload(a[1])
+        b.step_plain(aa, ab, obs, rew, term, trunc)
+        c = o.step(a[0], a[1])
+        np.testing.assert_array_equal(obs.download(), c["obs"]); np.testing.assert_array_equal(rew.download(), c["reward"])
+        np.testing.assert_array_equal(term.download(), c["terminated"]); np.testing.assert_array_equal(trunc.download(), c["truncated"])
+    assert_state_equal(b, o)
+    assert b.stats()[0].sum() == 0          # statistics are opt-in for single steps
+    b.close()
+
+
 def test_no_autoreset_freezes_finished_lanes_and_flags_misuse():
     n = 4096
     rng = np.random.default_rng(7)
