@@ -24,6 +24,27 @@ from ..core import SoccerBatch
 AGENTS = ('player_a', 'player_b')
 
 
+class _LazyInfo(dict):
+    """info[agent] in device mode: 'p' (a gather + a cast on the device) is computed on first access, so a
+    rollout loop that never looks at it does not pay two extra kernel launches per step."""
+    def __init__(self, make_p):
+        super().__init__()
+        self._make_p = make_p
+
+    def __missing__(self, key):
+        if key != "p":
+            raise KeyError(key)
+        v = self._make_p()
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return key == "p" or super().__contains__(key)
+
+    def keys(self):
+        return {"p"}.union(super().keys())
+
+
 class VectorSoccerEnv:
     metadata = {"render_modes": []}
 
@@ -145,9 +166,10 @@ class VectorSoccerEnv:
         b.step(a, bb, obs=self._obs, reward=self._rew, terminated=self._term, truncated=self._trunc,
                prob_code=self._code, final_obs=self._fin)
         r = self._rew.to(t.float32)
-        term = self._term.bool(); trunc = self._trunc.bool()
+        term = self._term.view(t.bool); trunc = self._trunc.view(t.bool)     # 0/1 bytes: reinterpret, no kernel
         ags = self.return_agent
-        infos = {ag: {"p": self._prob[self._code.long()]} for ag in ags}
+        lazy = _LazyInfo(lambda: self._prob[self._code.long()])
+        infos = {ag: lazy for ag in ags}
         infos["final_observation"] = {ag: self._fin for ag in ags}
         infos["_final_observation"] = term | trunc
         return ({ag: self._obs for ag in ags}, self._rewards(r),
