@@ -68,6 +68,8 @@ PROTOTYPES = {
     "soccer_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_uint64)]),
     "soccer_reset_stats": (C.c_int, [C.c_void_p]),
     "soccer_tick": (C.c_uint64, [C.c_void_p]),
+    "soccer_get_seed": (C.c_uint64, [C.c_void_p]),
+    "soccer_set_tick": (C.c_int, [C.c_void_p, C.c_uint64]),
     "soccer_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "soccer_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "soccer_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

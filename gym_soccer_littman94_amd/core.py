@@ -136,6 +136,19 @@ class SoccerBatch:
     def tick(self):
         return int(self.lib.soccer_tick(self.h))
 
+    # -- checkpoint / resume ---------------------------------------------------------------------
+    def checkpoint(self):
+        """Everything that determines the handle's future: the state streams, the Philox seed and the tick."""
+        ck = self.get_state()
+        ck["seed"] = int(self.lib.soccer_get_seed(self.h)); ck["tick"] = self.tick
+        return ck
+
+    def restore(self, ck):
+        self.set_state(ck["row_a"], ck["col_a"], ck["row_b"], ck["col_b"], ck["poss"], t=ck["t"],
+                       needs_reset=ck["needs_reset"])
+        self.seed(ck["seed"])
+        self._check(self.lib.soccer_set_tick(self.h, int(ck["tick"])))
+
     # -- tables ---------------------------------------------------------------------------------
     def tables(self):
         lut = np.zeros(self.lut_len, np.uint16)

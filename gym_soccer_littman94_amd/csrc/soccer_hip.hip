@@ -290,6 +290,21 @@ extern "C" int soccer_seed(soccer_handle* h, uint64_t seed) {
 
 extern "C" uint64_t soccer_tick(const soccer_handle* h) { return h ? h->tick : 0; }
 
+// checkpoint / resume: (state streams, seed, tick) fully determine every later result
+extern "C" int soccer_set_tick(soccer_handle* h, uint64_t tick) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_set_tick during graph capture");
+    if (tick >> 63) return fail(h, SOCCER_E_INVALID, "tick must be below 2^63");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    unsigned long long slots[32] = {0};
+    slots[0] = tick; slots[16] = tick;
+    HIP_TRY(h, hipMemcpy(h->d_tick, slots, sizeof slots, hipMemcpyHostToDevice));
+    h->tick = tick;
+    return SOCCER_OK;
+}
+extern "C" uint64_t soccer_get_seed(const soccer_handle* h) { return h ? h->cfg.seed : 0; }
+
 // the tick lives in device memory so that a captured graph advances it on every replay: launch j
 // reads slot (j & 1) and writes slot ((j + 1) & 1)
 static void bind_tick(soccer_handle* h, KernelParams& P, uint64_t ticks) {

@@ -191,6 +191,15 @@ class VectorSoccerEnv:
         self._batch.set_state(**kw)
         self._needs_reset = False
 
+    def checkpoint(self):
+        """State streams + Philox (seed, tick): restoring it on any VectorSoccerEnv of the same shape (and
+        lane_offset) reproduces every later step."""
+        return self._batch.checkpoint()
+
+    def restore(self, ck):
+        self._batch.restore(ck)
+        self._needs_reset = False
+
     def episode_histogram(self):
         """Counts of finished episodes by player A's return (-1, 0, +1)."""
         return self._batch.stats()[0]

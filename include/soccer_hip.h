@@ -222,6 +222,11 @@ int soccer_prob_table(const soccer_handle* h, double prob[12]);
 int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* misuse);
 int soccer_reset_stats(soccer_handle* h);
 uint64_t soccer_tick(const soccer_handle* h);
+/* Checkpoint / resume.  The reference keeps (state tuple, timestep, needs_reset, RandomState) per env; here
+ * the six state streams (soccer_get_state / soccer_set_state) plus (seed, tick) determine every later
+ * result of a handle, on any device count. */
+uint64_t soccer_get_seed(const soccer_handle* h);
+int soccer_set_tick(soccer_handle* h, uint64_t tick);
 
 /* ---- device memory + timing helpers (so a host without torch can drive the library) ------ */
 int soccer_malloc(soccer_handle* h, size_t bytes, void** dptr);

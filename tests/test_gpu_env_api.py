@@ -438,6 +438,27 @@ def test_vector_env_device_io_matches_numpy_io():
     vn.close(); vd.close()
 
 
+def test_checkpoint_resume_reproduces_the_future():
+    n = 4096
+    rng = np.random.default_rng(8)
+    acts = rng.integers(0, 5, size=(90, 2, n))
+    v = VectorSoccerEnv(n, slip_prob=0.2, seed=5)
+    v.reset()
+    for k in range(40):
+        v.step({'player_a': acts[k, 0], 'player_b': acts[k, 1]})
+    ck = v.checkpoint()
+    fut = [v.step({'player_a': acts[k, 0], 'player_b': acts[k, 1]}) for k in range(40, 90)]
+    w = VectorSoccerEnv(n, slip_prob=0.2, seed=123)           # a different env, different seed
+    w.restore(ck)
+    for k, ref in zip(range(40, 90), fut):
+        got = w.step({'player_a': acts[k, 0], 'player_b': acts[k, 1]})
+        np.testing.assert_array_equal(got[0]['player_a'], ref[0]['player_a'])
+        np.testing.assert_array_equal(got[1]['player_a'], ref[1]['player_a'])
+        np.testing.assert_array_equal(got[2]['player_a'], ref[2]['player_a'])
+        np.testing.assert_array_equal(got[3]['player_a'], ref[3]['player_a'])
+    v.close(); w.close()
+
+
 def test_make_ids():
     e = gsa.make("SoccerLittman94-v0")
     assert isinstance(e, SoccerSimultaneousEnv) and e.slip_prob == 0.0
