@@ -103,6 +103,62 @@ __global__ __launch_bounds__(256) void k_step_rolled(const KernelParams P, const
 }
 
 
+// LPT lanes per thread (1, 2 or 4) with the rolled lane loop, LEAN outputs: more waves for the same batch
+template <int LPT>
+__global__ __launch_bounds__(256) void k_step_lpt(const KernelParams P, const StepIO IO) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long i0 = g * LPT;
+    if (i0 + LPT > P.n) return;
+    const unsigned long long tick = *P.tick_in;
+    publish_tick(P, tick, 1ull);
+    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
+    const uint8_t* s = P.state;
+    auto ld = [&](const void* base) -> uint32_t {
+        const uint8_t* p = static_cast<const uint8_t*>(base) + i0;
+        if (LPT == 4) return *reinterpret_cast<const uint32_t*>(p);
+        if (LPT == 2) return *reinterpret_cast<const uint16_t*>(p);
+        return *p;
+    };
+    uint32_t ra = ld(s), ca = ld(s + P.state_stride), rb = ld(s + 2 * P.state_stride), cb = ld(s + 3 * P.state_stride);
+    uint32_t ps = ld(s + 4 * P.state_stride), tt = ld(s + 5 * P.state_stride), aa = ld(IO.act_a), ab = ld(IO.act_b);
+    const unsigned long long gl = P.lane_offset + i0;
+    const Philox4 blk = lane_block(P, gl >> 2, tick, 0u);
+    uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
+    bool mis = false;
+#pragma unroll 1
+    for (int j = 0; j < LPT; ++j) {
+        const uint32_t wi = ((uint32_t)gl + j) & 3u;
+        const uint32_t w = wi & 2 ? (wi & 1 ? blk.w[3] : blk.w[2]) : (wi & 1 ? blk.w[1] : blk.w[0]);
+        const uint32_t sh = 8u * j;
+        const uint32_t psj = __builtin_amdgcn_ubfe(ps, sh, 8u);
+        Lane L;
+        L.A = make_pos(__builtin_amdgcn_ubfe(ra, sh, 8u), __builtin_amdgcn_ubfe(ca, sh, 8u), P.W);
+        L.B = make_pos(__builtin_amdgcn_ubfe(rb, sh, 8u), __builtin_amdgcn_ubfe(cb, sh, 8u), P.W);
+        L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
+        StepResult R;
+        mis |= lane_step<false>(T, P, L, __builtin_amdgcn_ubfe(aa, sh, 8u), __builtin_amdgcn_ubfe(ab, sh, 8u), draw_from_word(w), R);
+        nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
+        nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
+        nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
+        o_rew = __builtin_amdgcn_alignbyte((uint32_t)R.reward & 0xffu, o_rew, 1);
+        o_term = __builtin_amdgcn_alignbyte(R.term, o_term, 1); o_trunc = __builtin_amdgcn_alignbyte(R.trunc, o_trunc, 1);
+        o_lo = __builtin_amdgcn_alignbit(o_hi, o_lo, 16); o_hi = (o_hi >> 16) | (R.obs << 16);
+    }
+    const int shb = 8 * (4 - LPT);
+    auto st8 = [&](void* base, uint32_t v) {
+        uint8_t* p = static_cast<uint8_t*>(base) + i0; v >>= shb;
+        if (LPT == 4) *reinterpret_cast<uint32_t*>(p) = v; else if (LPT == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)v; else *p = (uint8_t)v;
+    };
+    uint8_t* sw = P.state;
+    st8(sw, nra); st8(sw + P.state_stride, nca); st8(sw + 2 * P.state_stride, nrb); st8(sw + 3 * P.state_stride, ncb);
+    st8(sw + 4 * P.state_stride, nps); st8(sw + 5 * P.state_stride, ntt);
+    st8(IO.reward, o_rew); st8(IO.terminated, o_term); st8(IO.truncated, o_trunc);
+    if (LPT == 4) *reinterpret_cast<uint2*>(IO.obs + i0) = make_uint2(o_lo, o_hi);
+    else if (LPT == 2) *reinterpret_cast<uint32_t*>(IO.obs + i0) = o_hi;
+    else IO.obs[i0] = (uint16_t)(o_hi >> 16);
+    if (mis) *P.misuse = 1u;
+}
+
 // two groups per thread, software pipelined: all 16 loads up front, compute A, store A, compute B, store B
 struct G4 { uint32_t ra, ca, rb, cb, ps, tt, aa, ab; };
 __device__ __forceinline__ G4 load_g4(const KernelParams& P, const StepIO& IO, unsigned long long i0) {
@@ -220,6 +276,9 @@ int main(int argc, char** argv) {
     add("rolled E4 global hist    ", [&] { hipLaunchKernelGGL((k_step_rolled<false, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step (no last_ret)", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step LEAN         ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 256, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT4 (4096 waves)         ", [&] { hipLaunchKernelGGL((k_step_lpt<4>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT2 (8192 waves)         ", [&] { hipLaunchKernelGGL((k_step_lpt<2>), dim3(2048), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT1 (16384 waves)        ", [&] { hipLaunchKernelGGL((k_step_lpt<1>), dim3(4096), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step + step stats ", [&] { KernelParams Q = P; Q.step_stats = 1; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, Q, io_for(step)); });
     add("PRODUCT step + last_return", [&] { StepIO io = io_for(step); io.last_return = d_last; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io); });
     add("pipe2 hist               ", [&] { hipLaunchKernelGGL((k_step_pipe<true, 2>), dim3(512), dim3(256), 0, st, P, io_for(step)); });
