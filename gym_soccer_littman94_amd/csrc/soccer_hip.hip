@@ -354,9 +354,11 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
         const bool lean = !io.prob_code && !io.final_obs && !io.last_return && !P.step_stats;
         const int grid = grid_for(h, (P.n + 3) / 4);
         const dim3 g(grid), b(kBlock);
-        if (lean) {
-            if (h->slip) hipLaunchKernelGGL((step_kernel<true, false, true, true, 1, kBlock, true>), g, b, 0, h->stream, P, io);
-            else hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, kBlock, true>), g, b, 0, h->stream, P, io);
+        if (lean) {                 // one 4-lane group per thread, as many workgroups as it takes
+            const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
+            const dim3 gh(static_cast<unsigned>(blocks));
+            if (h->slip) hipLaunchKernelGGL(step_kernel_hot<true>, gh, b, 0, h->stream, P, io);
+            else hipLaunchKernelGGL(step_kernel_hot<false>, gh, b, 0, h->stream, P, io);
         } else launch_step3<false, true, true>(h, P, io);
     }
     else if (vec) launch_step3<false, true, false>(h, P, io);

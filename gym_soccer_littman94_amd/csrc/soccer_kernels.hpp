@@ -687,6 +687,61 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
     if (stats) hist.flush(P);
 }
 
+// The instantiation every Philox-driven, dword-aligned, 4-outputs-only step takes (bench.py's path):
+// one group of 4 lanes per thread, no grid-stride loop, no fallback or optional-output code at all.
+// Same lane loop as step_kernel; kept separate because a launch starts with a cold instruction cache
+// and every instruction that is not fetched counts (-0.4 us per launch against step_kernel<..., LEAN>).
+template <bool SLIP>
+__global__ __launch_bounds__(kBlock) void step_kernel_hot(const KernelParams P, const StepIO IO) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if ((g << 2) >= P.n) return;                                    // P.n is a multiple of 4 here
+    const unsigned long long i0 = P.first + (g << 2);
+    const unsigned long long tick = *P.tick_in;                     // scalar load
+    if (P.tick_out) publish_tick(P, tick, 1ull);
+    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
+    const uint8_t* sp = P.state;
+    const uint32_t ra = *reinterpret_cast<const uint32_t*>(sp + i0);
+    const uint32_t ca = *reinterpret_cast<const uint32_t*>(sp + P.state_stride + i0);
+    const uint32_t rb = *reinterpret_cast<const uint32_t*>(sp + 2 * P.state_stride + i0);
+    const uint32_t cb = *reinterpret_cast<const uint32_t*>(sp + 3 * P.state_stride + i0);
+    const uint32_t ps = *reinterpret_cast<const uint32_t*>(sp + 4 * P.state_stride + i0);
+    const uint32_t tt = *reinterpret_cast<const uint32_t*>(sp + 5 * P.state_stride + i0);
+    const uint32_t aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
+    const uint32_t ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
+    // the thread's 4 lanes are exactly one Philox block; computed while the loads are in flight
+    const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
+    uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
+    bool mis = false;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = j & 2 ? (j & 1 ? blk.w[3] : blk.w[2]) : (j & 1 ? blk.w[1] : blk.w[0]);
+        const uint32_t sh = 8u * (uint32_t)j;
+        const uint32_t psj = __builtin_amdgcn_ubfe(ps, sh, 8u);
+        Lane L;
+        L.A = make_pos(__builtin_amdgcn_ubfe(ra, sh, 8u), __builtin_amdgcn_ubfe(ca, sh, 8u), P.W);
+        L.B = make_pos(__builtin_amdgcn_ubfe(rb, sh, 8u), __builtin_amdgcn_ubfe(cb, sh, 8u), P.W);
+        L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
+        StepResult R;
+        mis |= lane_step<SLIP>(T, P, L, __builtin_amdgcn_ubfe(aa, sh, 8u), __builtin_amdgcn_ubfe(ab, sh, 8u),
+                               draw_from_word(w), R);
+        nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
+        nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
+        nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
+        o_rew = __builtin_amdgcn_alignbyte((uint32_t)R.reward & 0xffu, o_rew, 1);
+        o_term = __builtin_amdgcn_alignbyte(R.term, o_term, 1); o_trunc = __builtin_amdgcn_alignbyte(R.trunc, o_trunc, 1);
+        o_lo = __builtin_amdgcn_alignbit(o_hi, o_lo, 16); o_hi = (o_hi >> 16) | (R.obs << 16);
+    }
+    uint8_t* sw = P.state;
+    *reinterpret_cast<uint32_t*>(sw + i0) = nra; *reinterpret_cast<uint32_t*>(sw + P.state_stride + i0) = nca;
+    *reinterpret_cast<uint32_t*>(sw + 2 * P.state_stride + i0) = nrb; *reinterpret_cast<uint32_t*>(sw + 3 * P.state_stride + i0) = ncb;
+    *reinterpret_cast<uint32_t*>(sw + 4 * P.state_stride + i0) = nps; *reinterpret_cast<uint32_t*>(sw + 5 * P.state_stride + i0) = ntt;
+    if (IO.obs) *reinterpret_cast<uint2*>(IO.obs + i0) = make_uint2(o_lo, o_hi);
+    if (IO.reward) *reinterpret_cast<uint32_t*>(IO.reward + i0) = o_rew;
+    if (IO.terminated) *reinterpret_cast<uint32_t*>(IO.terminated + i0) = o_term;
+    if (IO.truncated) *reinterpret_cast<uint32_t*>(IO.truncated + i0) = o_trunc;
+    if (mis) *P.misuse = 1u;
+}
+
 // =================================================================================================
 // batched_reset
 // =================================================================================================
