@@ -4,6 +4,7 @@ This is the thin host layer between the gym-style classes (env.py, vector_env.py
 It never computes a transition itself: every step/reset is a kernel launch in libsoccer_hip.so.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -87,6 +88,7 @@ class SoccerBatch:
         that stream (0 = the device's default/null stream, which is what torch's default stream is)."""
         self.lib = _lib.load()
         self.h = None
+        self._arrays = weakref.WeakSet()        # device buffers handed out by alloc(); freed with the handle
         cfg = Config(n_lanes=int(n_lanes), width=int(width), height=int(height),
                      slip_prob=float(slip_prob), max_steps=int(max_steps), device=int(device),
                      seed=int(seed) & 0xFFFFFFFFFFFFFFFF, lane_offset=int(lane_offset),
@@ -114,6 +116,8 @@ class SoccerBatch:
 
     def close(self):
         if self.h:
+            for a in list(self._arrays):            # buffers that outlived their users: no leak past the handle
+                a.free()
             self.lib.soccer_destroy(self.h)
             self.h = None
 
@@ -124,7 +128,9 @@ class SoccerBatch:
             pass
 
     def alloc(self, shape, dtype):
-        return DeviceArray(self, shape, dtype)
+        a = DeviceArray(self, shape, dtype)
+        self._arrays.add(a)
+        return a
 
     def sync(self):
         self._check(self.lib.soccer_sync(self.h))

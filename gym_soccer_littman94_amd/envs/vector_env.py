@@ -87,6 +87,7 @@ class VectorSoccerEnv:
         self.action_space = spaces.Dict(
             {a: spaces.MultiDiscrete(np.full(self.num_envs, self.nA)) for a in ags})
         self._needs_reset = True
+        self._p_rounded = np.round(b.prob_table, 2)
         if io == "device":
             t, n, d = self._torch, self.num_envs, self._dev
             u16 = getattr(t, "uint16", t.int16)
@@ -151,10 +152,11 @@ class VectorSoccerEnv:
                 self._raise_on_misuse()
             r = out["reward"].astype(np.float32)
             term = out["terminated"].view(np.bool_); trunc = out["truncated"].view(np.bool_)
-            p = np.round(b.prob_table[out["prob_code"]], 2)
             fin_mask = term | trunc
             ags = self.return_agent
-            infos = {ag: {"p": p} for ag in ags}
+            code = out["prob_code"]
+            lazy = _LazyInfo(lambda: self._p_rounded[code])     # np.round(prob, 2) of the sampled transition (:405)
+            infos = {ag: lazy for ag in ags}
             infos["final_observation"] = {ag: out["final_obs"] for ag in ags}
             infos["_final_observation"] = fin_mask
             return ({ag: out["obs"] for ag in ags}, self._rewards(r),
