@@ -2,7 +2,7 @@
 //
 // What is evaluated per lane, and where the reference states it
 // (gym_soccer/envs/soccer_simultaneous_env.py):
-//   cell move via the LDS move/bounds table ............ _next_cell          :364-373
+//   cell move via the move/bounds table ................ _next_cell          :364-373
 //   ordered 5-way collision resolution ................. _get_next_state     :296-362
 //   nine slip combinations, float64 weights, zero-skip . :202-227, :241
 //   done / reward ...................................... :235-240
@@ -10,12 +10,17 @@
 //   bookkeeping (timestep, truncation, needs_reset) .... :396-406
 //   reset from the initial state distribution .......... :410-424
 //
-// Execution shape: wave64; each thread owns E consecutive lanes (environments) so that every SoA
-// byte stream is read and written with one 4/8-byte access per thread (coalesced 256/512 B per wave
-// instruction).  The first group's loads are issued BEFORE the rule tables are staged into LDS so
-// the two latencies overlap.  One Philox4x32-10 block serves four consecutive global lanes.
-// No MFMA: there is no contraction on this path.  The kernel is VALU-issue / launch-latency bound at
-// 2^20 lanes per launch and HBM bound by bytes (19 B per env-step).
+// Execution shape: wave64; each thread owns 4 (rollout: E = 1/4/8) consecutive lanes (environments) so
+// that every SoA byte stream is read and written with one dword (dwordx2) per thread — 256/512 B per
+// wave instruction.  One Philox4x32-10 block serves four consecutive global lanes.
+//   step_kernel_hot / step_kernel : one step per launch; rolled lane loop (small code: a launch starts
+//                                   with a cold instruction cache); rule tables read through L1/L2
+//   rollout_kernel                : T steps per launch with the state in registers; lane loop unrolled;
+//                                   rule tables staged in LDS once per workgroup
+//   reset_kernel, enumerate_kernel: reset from the ISD; the reference's transition table
+// No MFMA: there is no contraction on this path.  By bytes the kernels are HBM-bound (19 B per
+// env-step); measured, a single-step launch at 2^20 lanes is bound by launch latency plus ~130 vector
+// instructions per lane that do not overlap its load and store phases.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
