@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout", type=int, default=100, help="also time a fused T-step rollout (0 = skip)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearse the multi-rank path on fewer GPUs than ranks (ranks share devices, "
+                         "collectives go through host tensors); nccl (= RCCL over xGMI) is the real path")
     args = ap.parse_args()
 
     import torch
@@ -82,11 +85,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to bench)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gloo = args.dist_backend == "gloo"
+    dev_index = local_rank % torch.cuda.device_count() if gloo else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if gloo else dev          # where collective operands live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gym_soccer_littman94_amd import SoccerBatch
@@ -96,7 +105,7 @@ def main():
     assert lane_hi - lane_lo == N
     KG = K - (K % 2)                             # a captured sequence holds an even number of launches;
                                                  # an odd K adds one eager launch inside the timed region
-    b = SoccerBatch(N, 5, 4, args.slip, seed=0, autoreset=True, device=local_rank,
+    b = SoccerBatch(N, 5, 4, args.slip, seed=0, autoreset=True, device=dev_index,
                     lane_offset=lane_lo, envs_per_thread=args.envs_per_thread, step_stats=False)
 
     # synthetic inputs, resident in HBM before the timed region: uniform-random joint actions for
@@ -144,7 +153,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
 
@@ -159,17 +168,18 @@ def main():
     last_ret = torch.where(last_k > 0, rew[(last_k - 1).clamp(min=0), torch.arange(N, device=dev)],
                            torch.zeros((), dtype=torch.int8, device=dev))
     del kidx
-    if world > 1:
-        gathered = gather_lane_values(last_ret, world * N)      # RCCL all_gather over xGMI, int8[N] per rank
-        hist = np.array(reduce_histogram(hist, device=dev))
-    else:
-        gathered = last_ret
-    # cheap end-to-end sanity on the real outputs of the timed steps (not a parity test)
+    # cheap end-to-end sanity on this rank's real outputs of the timed steps (not a parity test)
     n_fin = int(fin.sum()); r_sum = int(rew.to(torch.int32).sum())
     assert n_fin < K * N and abs(r_sum) <= n_fin and int(hist.sum()) == n_fin, "implausible outputs"
     assert int(obs.max()) < b.nS and int(rew.abs().max()) <= 1
     if K >= 50:                     # long enough for goals to have been scored
         assert n_fin > 0 and int(rew.abs().max()) == 1, "implausible outputs"
+    if world > 1:
+        gathered = gather_lane_values(last_ret.to(cdev), world * N)   # RCCL all_gather over xGMI, int8[N] per rank
+        hist = np.array(reduce_histogram(hist, device=cdev))
+        assert gathered.numel() == world * N
+    else:
+        gathered = last_ret
     del fin
 
     # ---- optional: fused T-step rollout (state in registers, same per-step results) -------------
@@ -187,7 +197,7 @@ def main():
             reps.append(b.timer_stop())
         r_ms = sorted(reps)[len(reps) // 2]
         if world > 1:
-            tt = torch.tensor([r_ms], dtype=torch.float64, device=dev)
+            tt = torch.tensor([r_ms], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX); r_ms = float(tt[0])
         bytes_per = 7 + 12.0 / T                         # 2 B actions in, 5 B out, state amortised over T
         rollout = {"steps_fused": T, "env_steps_per_s": world * N * T / (r_ms * 1e-3),
@@ -212,9 +222,9 @@ def main():
         s_ms = sorted(reps)[1]
         h1 = b.stats()[0].astype(np.int64)
         if world > 1:
-            tt = torch.tensor([s_ms], dtype=torch.float64, device=dev)
+            tt = torch.tensor([s_ms], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX); s_ms = float(tt[0])
-            hsum = np.array(reduce_histogram(h1 - h0, device=dev))
+            hsum = np.array(reduce_histogram(h1 - h0, device=cdev))
         else:
             hsum = h1 - h0
         selfplay = {"horizon": T, "env_steps_per_s": world * N * T / (s_ms * 1e-3),
@@ -225,7 +235,7 @@ def main():
         achieved = ALGO_BYTES_PER_ENV_STEP * N / launch_s / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")   # from a separate rocprofv3 --pmc run
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and N == (1 << 20) and args.slip == 0.0:   # measured for exactly this workload
             try:
                 traffic = json.load(open(tfile)).get("step_kernel_hbm_bytes_per_launch")
             except Exception:
