@@ -104,8 +104,15 @@ __global__ __launch_bounds__(256) void k_step_rolled(const KernelParams P, const
 
 
 // LPT lanes per thread (1, 2 or 4) with the rolled lane loop, LEAN outputs: more waves for the same batch
-template <int LPT>
+// STAG: which workgroups start late (0 none, 1: (b>>8)&1, 2: b&1, 3: (b>>9)&1, 4: wave parity within the block);
+// SLEEP: s_sleep argument (x64 cycles).  Late starters load while early ones compute, store while late compute.
+template <int LPT, int STAG = 0, int SLEEP = 0>
 __global__ __launch_bounds__(256) void k_step_lpt(const KernelParams P, const StepIO IO) {
+    if (STAG) {
+        const bool late = STAG == 1 ? ((blockIdx.x >> 8) & 1) : STAG == 2 ? (blockIdx.x & 1) : STAG == 3 ? ((blockIdx.x >> 9) & 1)
+                                                                                           : ((threadIdx.x >> 6) & 1);
+        if (late) __builtin_amdgcn_s_sleep(SLEEP);
+    }
     const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     const unsigned long long i0 = g * LPT;
     if (i0 + LPT > P.n) return;
@@ -277,6 +284,14 @@ int main(int argc, char** argv) {
     add("PRODUCT step (no last_ret)", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step LEAN         ", [&] { hipLaunchKernelGGL((step_kernel<false, false, true, true, 1, 256, true>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
     add("LPT4 (4096 waves)         ", [&] { hipLaunchKernelGGL((k_step_lpt<4>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT4 stag b>>8 sleep20    ", [&] { hipLaunchKernelGGL((k_step_lpt<4, 1, 20>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT4 stag b>>8 sleep40    ", [&] { hipLaunchKernelGGL((k_step_lpt<4, 1, 40>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT4 stag b>>8 sleep70    ", [&] { hipLaunchKernelGGL((k_step_lpt<4, 1, 70>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT4 stag b&1  sleep40    ", [&] { hipLaunchKernelGGL((k_step_lpt<4, 2, 40>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT4 stag b>>9 sleep40    ", [&] { hipLaunchKernelGGL((k_step_lpt<4, 3, 40>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT4 stag wave&1 sleep40  ", [&] { hipLaunchKernelGGL((k_step_lpt<4, 4, 40>), dim3(1024), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT2 stag b>>9 sleep40    ", [&] { hipLaunchKernelGGL((k_step_lpt<2, 3, 40>), dim3(2048), dim3(256), 0, st, P, io_for(step)); });
+    add("LPT2 stag b&1 sleep40     ", [&] { hipLaunchKernelGGL((k_step_lpt<2, 2, 40>), dim3(2048), dim3(256), 0, st, P, io_for(step)); });
     add("LPT2 (8192 waves)         ", [&] { hipLaunchKernelGGL((k_step_lpt<2>), dim3(2048), dim3(256), 0, st, P, io_for(step)); });
     add("LPT1 (16384 waves)        ", [&] { hipLaunchKernelGGL((k_step_lpt<1>), dim3(4096), dim3(256), 0, st, P, io_for(step)); });
     add("PRODUCT step + step stats ", [&] { KernelParams Q = P; Q.step_stats = 1; hipLaunchKernelGGL((step_kernel<false, false, true, true>), dim3(1024), dim3(256), 0, st, Q, io_for(step)); });
