@@ -104,6 +104,9 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 // the block shared by global lanes 4q .. 4q+3 at `tick`; purpose 0 = step/reset, 1 = sampled actions
 __device__ __forceinline__ Philox4 lane_block(const KernelParams& P, unsigned long long q,
                                               unsigned long long tick, uint32_t purpose) {
+#ifdef SOCCER_LAB_NO_PHILOX     // tools/kernel_lab.hip ablation build only
+    return Philox4{{(uint32_t)q * 2654435761u, (uint32_t)tick, (uint32_t)q ^ 0x9E3779B9u, purpose}};
+#endif
     return philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick,
                          (uint32_t)(tick >> 32) | (purpose << 31), P.key0, P.key1);
 }
@@ -180,6 +183,9 @@ __device__ __forceinline__ uint32_t col_of(uint32_t pos) { return (pos >> 16) & 
 // Rules::build, which checks the table against it — but the kernels are VALU-bound and the gather
 // rides the memory pipe: the ~12 extra vector instructions measured 4 % slower per step.
 __device__ __forceinline__ uint32_t obs_of(const Tables& T, const KernelParams& P, uint32_t A, uint32_t B, uint32_t p) {
+#ifdef SOCCER_LAB_NO_GATHER
+    return (mad24(cell_of(A), (uint32_t)P.HW, cell_of(B)) << 1) | p;
+#endif
     return T.lut[(mad24(cell_of(A), (uint32_t)P.HW, cell_of(B)) << 1) | p];
 }
 
@@ -197,6 +203,9 @@ struct Resolved { uint32_t kind, nA, nB; };
 
 // the cell a player reaches with one move (_next_cell :364-373, via the move/bounds table)
 __device__ __forceinline__ uint32_t moved(const Tables& T, const KernelParams& P, uint32_t pos, uint32_t has_ball, uint32_t mv) {
+#ifdef SOCCER_LAB_NO_GATHER     // tools/kernel_lab.hip ablation build only
+    return pos + (mv == 3u ? 0x00010001u : 0u) * (has_ball & 1u);
+#endif
     return T.nc[mad24(has_ball, (uint32_t)P.HW5, mad24(cell_of(pos), 5u, mv))];
 }
 
