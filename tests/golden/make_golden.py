@@ -261,7 +261,7 @@ def main():
     print("reference imported from", REF)
     for (w, h, s, nrep) in [(5, 4, 0.0, 20000), (5, 4, 0.2, 20000), (5, 4, 0.5, 4000),
                             (5, 4, 1.0, 4000), (6, 4, 0.0, 4000), (7, 5, 0.0, 4000),
-                            (7, 5, 0.3, 4000)]:
+                            (7, 5, 0.3, 4000), (9, 6, 0.0, 4000)]:
         env = dump_table(Env, w, h, s)
         dump_replay(env, w, h, s, nrep, seed=1000 + w * 10 + h)
         if s == 0.0:

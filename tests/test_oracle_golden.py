@@ -22,7 +22,7 @@ def _ids(paths):
 
 
 def test_fixtures_present():
-    assert len(TABLES) >= 7 and len(REPLAYS) >= 7 and len(RESETS) >= 3 and len(TRAJS) >= 4
+    assert len(TABLES) >= 8 and len(REPLAYS) >= 8 and len(RESETS) >= 4 and len(TRAJS) >= 4
 
 
 def test_philox_known_answers():
