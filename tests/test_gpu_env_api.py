@@ -63,6 +63,18 @@ def test_same_seed_reproduces_reference_trajectories(path):
     env.close()
 
 
+def test_survey_appendix_b_seed7_vector(slip_env):
+    """SURVEY.md Appendix B (measured on the reference, independent of tests/golden): slip_prob=0.2,
+    reset(seed=7), then actions (k%5, 3k%5) for k = 0..9."""
+    o, _ = slip_env.reset(seed=7)
+    assert o['player_a'] == 253
+    seen = []
+    for k in range(10):
+        o, r, d, t, i = slip_env.step({'player_a': k % 5, 'player_b': (3 * k) % 5})
+        seen.append(o['player_a'])
+    assert seen == [253, 65, 253, 453, 415, 415, 227, 407, 443, 403]
+
+
 # ---- known-answer vectors of the reference's deterministic tests ---------------------------------
 def test_initialization_and_shapes(env):
     assert env.width == 7 and env.height == 4 and env.slip_prob == 0.0
