@@ -42,6 +42,13 @@ class RolloutArgs(C.Structure):
                 ("mix_a", C.c_void_p), ("mix_b", C.c_void_p)]
 
 
+class StagingView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("act_a", "act_b", "mask", "u_step", "u_reset", "obs", "final_obs",
+                                         "reward", "terminated", "truncated", "prob_code")]
+
+
+STAGE_ACT_A, STAGE_ACT_B, STAGE_U_STEP, STAGE_U_RESET, STAGE_MASK = 1, 2, 4, 8, 16
+
 # name -> (restype, argtypes); every symbol include/soccer_hip.h declares
 PROTOTYPES = {
     "soccer_abi_version": (C.c_int, []),
@@ -57,6 +64,9 @@ PROTOTYPES = {
     "batched_rollout": (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs)]),
     "batched_step_host": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
     "batched_reset_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "soccer_staging": (C.c_int, [C.c_void_p, C.POINTER(StagingView)]),
+    "batched_step_staged": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "batched_reset_staged": (C.c_int, [C.c_void_p, C.c_uint32]),
     "soccer_set_policy": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "soccer_host_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "soccer_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),

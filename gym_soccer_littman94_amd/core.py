@@ -216,6 +216,35 @@ class SoccerBatch:
             else np.ascontiguousarray(policy, dtype=np.int8)
         self._check(self.lib.soccer_set_policy(self.h, idx, arr.ctypes.data, int(arr.size)))
 
+    # -- zero-copy staged I/O: numpy views over the handle's pinned staging block ----------------
+    def staging(self):
+        """dict of numpy arrays (length n) over the pinned staging block: inputs act_a, act_b, mask, u_step,
+        u_reset; outputs obs, final_obs, reward, terminated, truncated, prob_code (overwritten by the
+        next staged call)."""
+        if getattr(self, "_staging", None) is None:
+            v = _lib.StagingView()
+            self._check(self.lib.soccer_staging(self.h, C.byref(v)))
+            def view(ptr, dt):
+                dt = np.dtype(dt)
+                buf = (C.c_uint8 * (self.n * dt.itemsize)).from_address(ptr)
+                return np.frombuffer(buf, dtype=dt)
+            self._staging = {"act_a": view(v.act_a, np.int8), "act_b": view(v.act_b, np.int8),
+                             "mask": view(v.mask, np.uint8), "u_step": view(v.u_step, np.float64),
+                             "u_reset": view(v.u_reset, np.float64), "obs": view(v.obs, np.uint16),
+                             "final_obs": view(v.final_obs, np.uint16), "reward": view(v.reward, np.int8),
+                             "terminated": view(v.terminated, np.uint8), "truncated": view(v.truncated, np.uint8),
+                             "prob_code": view(v.prob_code, np.uint8)}
+        return self._staging
+
+    def step_staged(self, act_a=True, act_b=True, u_step=False, u_reset=False):
+        use = (_lib.STAGE_ACT_A if act_a else 0) | (_lib.STAGE_ACT_B if act_b else 0) | \
+              (_lib.STAGE_U_STEP if u_step else 0) | (_lib.STAGE_U_RESET if u_reset else 0)
+        self._check(self.lib.batched_step_staged(self.h, use))
+
+    def reset_staged(self, mask=False, u_reset=False):
+        self._check(self.lib.batched_reset_staged(self.h, (_lib.STAGE_MASK if mask else 0) |
+                                                  (_lib.STAGE_U_RESET if u_reset else 0)))
+
     # -- host-array variants (numpy in, numpy out; one staged copy each way) -------------------
     def reset_host(self, mask=None, u_reset=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

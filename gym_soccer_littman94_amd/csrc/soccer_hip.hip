@@ -536,20 +536,20 @@ extern "C" int soccer_get_state(soccer_handle* h, int8_t* row_a, int8_t* col_a, 
 // ---- host-pointer entry points: stage through one pinned block, one copy each way ---------------
 namespace {
 struct StageLayout {
-    size_t act_a, act_b, u_step, u_reset, mask;            // inputs
+    size_t act_a, act_b, mask, u_step, u_reset;            // inputs (the action streams first: they always travel)
     size_t obs, final_obs, reward, term, trunc, code;      // outputs
-    size_t in_bytes, total;
+    size_t out_begin, total;
 };
 StageLayout stage_layout(size_t n) {
     auto up = [](size_t x) { return (x + 63) & ~size_t(63); };
     StageLayout L{};
     size_t o = 0;
-    L.u_step = o; o = up(o + 8 * n);
-    L.u_reset = o; o = up(o + 8 * n);
     L.act_a = o; o = up(o + n);
     L.act_b = o; o = up(o + n);
     L.mask = o; o = up(o + n);
-    L.in_bytes = o;
+    L.u_step = o; o = up(o + 8 * n);
+    L.u_reset = o; o = up(o + 8 * n);
+    L.out_begin = o;
     L.obs = o; o = up(o + 2 * n);
     L.final_obs = o; o = up(o + 2 * n);
     L.reward = o; o = up(o + n);
@@ -573,59 +573,106 @@ int ensure_stage(soccer_handle* h, const StageLayout& L) {
 }
 }  // namespace
 
-extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {
+extern "C" int soccer_staging(soccer_handle* h, soccer_staging_view* v) {
+    if (!h || !v) return fail(h, SOCCER_E_INVALID, "handle/view is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const StageLayout L = stage_layout(h->P.n);
+    if (int rc = ensure_stage(h, L)) return rc;
+    uint8_t* H = h->stage_host;
+    v->act_a = reinterpret_cast<int8_t*>(H + L.act_a); v->act_b = reinterpret_cast<int8_t*>(H + L.act_b);
+    v->mask = H + L.mask;
+    v->u_step = reinterpret_cast<double*>(H + L.u_step); v->u_reset = reinterpret_cast<double*>(H + L.u_reset);
+    v->obs = reinterpret_cast<uint16_t*>(H + L.obs); v->final_obs = reinterpret_cast<uint16_t*>(H + L.final_obs);
+    v->reward = reinterpret_cast<int8_t*>(H + L.reward); v->terminated = H + L.term; v->truncated = H + L.trunc;
+    v->prob_code = H + L.code;
+    return SOCCER_OK;
+}
+
+extern "C" int batched_step_staged(soccer_handle* h, uint32_t use) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
-    if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_step_host during graph capture");
-    if (!a || (!a->act_a && !h->P.policy_a) || (!a->act_b && !h->P.policy_b))
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_step_staged during graph capture");
+    const bool has_a = use & SOCCER_STAGE_ACT_A, has_b = use & SOCCER_STAGE_ACT_B;
+    if ((!has_a && !h->P.policy_a) || (!has_b && !h->P.policy_b))
         return fail(h, SOCCER_E_INVALID, "batched_step: an action stream is required for every player without a fixed policy");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t n = h->P.n;
     const StageLayout L = stage_layout(n);
     if (int rc = ensure_stage(h, L)) return rc;
     uint8_t* H = h->stage_host; uint8_t* D = h->stage_dev;
-    if (a->act_a) std::memcpy(H + L.act_a, a->act_a, n);
-    if (a->act_b) std::memcpy(H + L.act_b, a->act_b, n);
-    if (a->u_step) std::memcpy(H + L.u_step, a->u_step, 8 * n);
-    if (a->u_reset) std::memcpy(H + L.u_reset, a->u_reset, 8 * n);
-    if (!h->mapped) HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
+    if (!h->mapped) {           // only what this call uses crosses the bus
+        if (has_a && has_b) HIP_TRY(h, hipMemcpyAsync(D + L.act_a, H + L.act_a, L.act_b + n - L.act_a, hipMemcpyHostToDevice, h->stream));
+        else if (has_a) HIP_TRY(h, hipMemcpyAsync(D + L.act_a, H + L.act_a, n, hipMemcpyHostToDevice, h->stream));
+        else if (has_b) HIP_TRY(h, hipMemcpyAsync(D + L.act_b, H + L.act_b, n, hipMemcpyHostToDevice, h->stream));
+        if (use & SOCCER_STAGE_U_STEP) HIP_TRY(h, hipMemcpyAsync(D + L.u_step, H + L.u_step, 8 * n, hipMemcpyHostToDevice, h->stream));
+        if (use & SOCCER_STAGE_U_RESET) HIP_TRY(h, hipMemcpyAsync(D + L.u_reset, H + L.u_reset, 8 * n, hipMemcpyHostToDevice, h->stream));
+    }
     soccer_step_args d{};
-    d.act_a = a->act_a ? reinterpret_cast<const int8_t*>(D + L.act_a) : nullptr;
-    d.act_b = a->act_b ? reinterpret_cast<const int8_t*>(D + L.act_b) : nullptr;
-    d.u_step = a->u_step ? reinterpret_cast<const double*>(D + L.u_step) : nullptr;
-    d.u_reset = a->u_reset ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr;
+    d.act_a = has_a ? reinterpret_cast<const int8_t*>(D + L.act_a) : nullptr;
+    d.act_b = has_b ? reinterpret_cast<const int8_t*>(D + L.act_b) : nullptr;
+    d.u_step = (use & SOCCER_STAGE_U_STEP) ? reinterpret_cast<const double*>(D + L.u_step) : nullptr;
+    d.u_reset = (use & SOCCER_STAGE_U_RESET) ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr;
     d.obs = reinterpret_cast<uint16_t*>(D + L.obs); d.final_obs = reinterpret_cast<uint16_t*>(D + L.final_obs);
     d.reward = reinterpret_cast<int8_t*>(D + L.reward); d.terminated = D + L.term; d.truncated = D + L.trunc;
     d.prob_code = D + L.code;
-    if (a->last_return) return fail(h, SOCCER_E_INVALID, "batched_step_host: last_return is device-only");
     if (int rc = batched_step_ex(h, &d)) return rc;
-    if (!h->mapped) HIP_TRY(h, hipMemcpyAsync(H + L.in_bytes, D + L.in_bytes, L.total - L.in_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (!h->mapped) HIP_TRY(h, hipMemcpyAsync(H + L.out_begin, D + L.out_begin, L.total - L.out_begin, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (a->obs) std::memcpy(a->obs, H + L.obs, 2 * n);
-    if (a->final_obs) std::memcpy(a->final_obs, H + L.final_obs, 2 * n);
-    if (a->reward) std::memcpy(a->reward, H + L.reward, n);
-    if (a->terminated) std::memcpy(a->terminated, H + L.term, n);
-    if (a->truncated) std::memcpy(a->truncated, H + L.trunc, n);
-    if (a->prob_code) std::memcpy(a->prob_code, H + L.code, n);
     return SOCCER_OK;
 }
 
-extern "C" int batched_reset_host(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs) {
+extern "C" int batched_reset_staged(soccer_handle* h, uint32_t use) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
-    if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_reset_host during graph capture");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_reset_staged during graph capture");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t n = h->P.n;
     const StageLayout L = stage_layout(n);
     if (int rc = ensure_stage(h, L)) return rc;
     uint8_t* H = h->stage_host; uint8_t* D = h->stage_dev;
-    if (mask) std::memcpy(H + L.mask, mask, n);
-    if (u_reset) std::memcpy(H + L.u_reset, u_reset, 8 * n);
-    if ((mask || u_reset) && !h->mapped) HIP_TRY(h, hipMemcpyAsync(D, H, L.in_bytes, hipMemcpyHostToDevice, h->stream));
-    if (int rc = batched_reset(h, mask ? D + L.mask : nullptr,
-                               u_reset ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr,
+    if (!h->mapped) {
+        if (use & SOCCER_STAGE_MASK) HIP_TRY(h, hipMemcpyAsync(D + L.mask, H + L.mask, n, hipMemcpyHostToDevice, h->stream));
+        if (use & SOCCER_STAGE_U_RESET) HIP_TRY(h, hipMemcpyAsync(D + L.u_reset, H + L.u_reset, 8 * n, hipMemcpyHostToDevice, h->stream));
+    }
+    if (int rc = batched_reset(h, (use & SOCCER_STAGE_MASK) ? D + L.mask : nullptr,
+                               (use & SOCCER_STAGE_U_RESET) ? reinterpret_cast<const double*>(D + L.u_reset) : nullptr,
                                reinterpret_cast<uint16_t*>(D + L.obs))) return rc;
     if (!h->mapped) HIP_TRY(h, hipMemcpyAsync(H + L.obs, D + L.obs, 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (obs) std::memcpy(obs, H + L.obs, 2 * n);
+    return SOCCER_OK;
+}
+
+// host arrays in, host arrays out: copies through the staging block around the *_staged calls
+extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (!a) return fail(h, SOCCER_E_INVALID, "batched_step: arguments are NULL");
+    if (a->last_return) return fail(h, SOCCER_E_INVALID, "batched_step_host: last_return is device-only");
+    soccer_staging_view v{};
+    if (int rc = soccer_staging(h, &v)) return rc;
+    const size_t n = h->P.n;
+    uint32_t use = 0;
+    if (a->act_a) { std::memcpy(v.act_a, a->act_a, n); use |= SOCCER_STAGE_ACT_A; }
+    if (a->act_b) { std::memcpy(v.act_b, a->act_b, n); use |= SOCCER_STAGE_ACT_B; }
+    if (a->u_step) { std::memcpy(v.u_step, a->u_step, 8 * n); use |= SOCCER_STAGE_U_STEP; }
+    if (a->u_reset) { std::memcpy(v.u_reset, a->u_reset, 8 * n); use |= SOCCER_STAGE_U_RESET; }
+    if (int rc = batched_step_staged(h, use)) return rc;
+    if (a->obs) std::memcpy(a->obs, v.obs, 2 * n);
+    if (a->final_obs) std::memcpy(a->final_obs, v.final_obs, 2 * n);
+    if (a->reward) std::memcpy(a->reward, v.reward, n);
+    if (a->terminated) std::memcpy(a->terminated, v.terminated, n);
+    if (a->truncated) std::memcpy(a->truncated, v.truncated, n);
+    if (a->prob_code) std::memcpy(a->prob_code, v.prob_code, n);
+    return SOCCER_OK;
+}
+
+extern "C" int batched_reset_host(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    soccer_staging_view v{};
+    if (int rc = soccer_staging(h, &v)) return rc;
+    const size_t n = h->P.n;
+    uint32_t use = 0;
+    if (mask) { std::memcpy(v.mask, mask, n); use |= SOCCER_STAGE_MASK; }
+    if (u_reset) { std::memcpy(v.u_reset, u_reset, 8 * n); use |= SOCCER_STAGE_U_RESET; }
+    if (int rc = batched_reset_staged(h, use)) return rc;
+    if (obs) std::memcpy(obs, v.obs, 2 * n);
     return SOCCER_OK;
 }
 

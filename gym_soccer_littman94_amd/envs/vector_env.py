@@ -10,8 +10,9 @@ reference leaves undefined:
   * rewards float32 (+r for player_a, -r for player_b, :400-402), terminated/truncated bool.
 
 Two I/O modes:
-  * numpy (default): actions are host arrays; results come back as numpy arrays (one staged copy
-    in, one kernel, one staged copy out per step);
+  * numpy (default): actions are host arrays; results are numpy views over the handle's pinned
+    staging block when `copy=False` (one copy in, one kernel, one copy out over PCIe per step; valid
+    until the next step()), private copies with the default `copy=True` (gym.vector's convention);
   * device: actions are torch CUDA int8 tensors; results are torch tensors living in buffers the env
     owns, nothing is synchronised — the mode for rollout loops that stay on the GPU.
 Per-lane randomness is Philox4x32-10 keyed by (seed, global lane id, tick): include/soccer_hip.h.
@@ -50,13 +51,14 @@ class VectorSoccerEnv:
 
     def __init__(self, num_envs, width=5, height=4, slip_prob=0.0, seed=0, autoreset=True,
                  device=0, lane_offset=0, max_episode_steps=100, io="numpy", strict=True,
-                 envs_per_thread=0, player_a_policy=None, player_b_policy=None):
+                 envs_per_thread=0, player_a_policy=None, player_b_policy=None, copy=True):
         assert io in ("numpy", "device"), "io must be 'numpy' or 'device'"
         assert not (player_a_policy is not None and player_b_policy is not None), \
             "Both players cannot have a policy. At least one must be None."
         self.num_envs = int(num_envs)
         self.io = io
         self.strict = strict
+        self.copy = bool(copy)      # numpy io: return copies (gym.vector's default) or views over the staging block
         stream = None
         if io == "device":
             import torch
@@ -139,15 +141,19 @@ class VectorSoccerEnv:
         b = self._batch
         n = self.num_envs
         if self.io == "numpy":
-            acts = []
-            for x in (a, bb):
+            # actions are written straight into the handle's pinned staging block and the results are
+            # views over it (valid until the next step): nothing is copied on the host side
+            stg = b.staging()
+            for key, x in (("act_a", a), ("act_b", bb)):
                 if x is None:
-                    acts.append(None); continue
+                    continue
                 x = np.asarray(x)
                 assert x.shape == (n,), "one action per environment and agent"
                 assert ((x >= 0) & (x < self.nA)).all(), "actions must be in 0..4"
-                acts.append(x.astype(np.int8, copy=False))
-            out = b.step_host(acts[0], acts[1])
+                np.copyto(stg[key], x, casting="unsafe")
+            b.step_staged(act_a=a is not None, act_b=bb is not None)
+            out = {k: stg[k].copy() for k in ("obs", "final_obs", "reward", "terminated", "truncated", "prob_code")} \
+                if self.copy else stg
             if self.strict:
                 self._raise_on_misuse()
             r = out["reward"].astype(np.float32)

@@ -172,6 +172,24 @@ int batched_rollout(soccer_handle* h, const soccer_rollout_args* args);
 int batched_step_host(soccer_handle* h, const soccer_step_args* host_args);
 int batched_reset_host(soccer_handle* h, const uint8_t* mask, const double* u_reset, uint16_t* obs);
 
+/* Zero-copy form of the above: the caller fills the input arrays of the handle's pinned staging block
+ * (soccer_staging gives their HOST addresses, n_lanes elements each, valid for the handle's lifetime),
+ * calls batched_step_staged / batched_reset_staged with the SOCCER_STAGE_* bits of the inputs it filled,
+ * and reads the results from the block's output arrays (overwritten by the next staged call). */
+#define SOCCER_STAGE_ACT_A   1u
+#define SOCCER_STAGE_ACT_B   2u
+#define SOCCER_STAGE_U_STEP  4u
+#define SOCCER_STAGE_U_RESET 8u
+#define SOCCER_STAGE_MASK    16u
+typedef struct soccer_staging_view {
+    int8_t* act_a; int8_t* act_b; uint8_t* mask; double* u_step; double* u_reset;          /* inputs  */
+    uint16_t* obs; uint16_t* final_obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
+    uint8_t* prob_code;                                                                      /* outputs */
+} soccer_staging_view;
+int soccer_staging(soccer_handle* h, soccer_staging_view* view);
+int batched_step_staged(soccer_handle* h, uint32_t inputs);
+int batched_reset_staged(soccer_handle* h, uint32_t inputs);
+
 /* Single-agent mode (reference :54-56, :187-188, :266-279): `player` (0 = player_a, 1 = player_b) follows
  * a fixed policy — HOST int8[n_states], action per observation index — looked up with the observation
  * of the CURRENT tuple before every step; that player's action stream may then be NULL.  Only one

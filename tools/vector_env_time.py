@@ -8,15 +8,16 @@ from gym_soccer_littman94_amd import VectorSoccerEnv
 
 for n in (1 << 16, 1 << 20):
     rng = np.random.default_rng(0)
-    v = VectorSoccerEnv(n, seed=0)
-    v.reset()
     a = rng.integers(0, 5, size=(8, 2, n)).astype(np.int8)
-    for k in range(3): v.step({'player_a': a[k, 0], 'player_b': a[k, 1]})
-    t = time.perf_counter(); K = 30
-    for k in range(K): v.step({'player_a': a[k % 8, 0], 'player_b': a[k % 8, 1]})
-    dt = time.perf_counter() - t
-    print("numpy  io  n=%8d: %8.1f us/step  %.3g env-steps/s" % (n, dt / K * 1e6, n * K / dt))
-    v.close()
+    for copy in (True, False):
+        v = VectorSoccerEnv(n, seed=0, copy=copy)
+        v.reset()
+        for k in range(3): v.step({'player_a': a[k, 0], 'player_b': a[k, 1]})
+        t = time.perf_counter(); K = 30
+        for k in range(K): v.step({'player_a': a[k % 8, 0], 'player_b': a[k % 8, 1]})
+        dt = time.perf_counter() - t
+        print("numpy  io  n=%8d copy=%-5s: %8.1f us/step  %.3g env-steps/s" % (n, copy, dt / K * 1e6, n * K / dt))
+        v.close()
     v = VectorSoccerEnv(n, seed=0, io="device")
     v.reset()
     ta = torch.from_numpy(a).cuda()
