@@ -163,8 +163,9 @@ def main():
     assert misuse == 0
     fin = (term | trunc) != 0
     hist = np.array([int(((rew == v) & fin).sum()) for v in (-1, 0, 1)], dtype=np.int64)
-    kidx = torch.arange(1, K + 1, dtype=torch.int16, device=dev)[:, None]
-    last_k = (fin.to(torch.int16) * kidx).amax(0).long()                 # last step at which the lane's episode ended
+    kdt = torch.int16 if K < 32000 else torch.int32
+    kidx = torch.arange(1, K + 1, dtype=kdt, device=dev)[:, None]
+    last_k = (fin.to(kdt) * kidx).amax(0).long()                 # last step at which the lane's episode ended
     last_ret = torch.where(last_k > 0, rew[(last_k - 1).clamp(min=0), torch.arange(N, device=dev)],
                            torch.zeros((), dtype=torch.int8, device=dev))
     del kidx
