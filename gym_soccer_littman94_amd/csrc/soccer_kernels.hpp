@@ -501,8 +501,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // (the rollout kernel, which would pay 6 live VGPRs — and an occupancy step — for nothing).
 template <bool EARLY>
 struct HistAcc {
-    uint32_t fp;            // this thread's finished episodes: all | (return +1) << 16
-    uint32_t ng;            // ... with return -1
+    uint32_t fin, pos, neg;     // this thread's finished episodes: all / return +1 / return -1
     ulonglong2 old01; unsigned long long old2;   // EARLY only: the wave's slot as of kernel entry (lane 0)
     __device__ __forceinline__ unsigned long long* slot(const KernelParams& P) const {
         const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -511,7 +510,7 @@ struct HistAcc {
     // Every wave of a launch owns one slot and launches are stream-ordered, so plain loads and stores
     // accumulate without atomics.
     __device__ __forceinline__ void init(const KernelParams& P) {
-        fp = 0u; ng = 0u;
+        fin = 0u; pos = 0u; neg = 0u;
         if (EARLY) {
             old01 = make_ulonglong2(0ull, 0ull); old2 = 0ull;
             if ((threadIdx.x & 63u) == 0u) {
@@ -521,18 +520,21 @@ struct HistAcc {
         }
     }
     __device__ __forceinline__ void add(uint32_t finished, int32_t reward) {
-        fp += finished + (reward > 0 ? (1u << 16) : 0u);
-        ng += reward < 0 ? 1u : 0u;
+        fin += finished; pos += reward > 0 ? 1u : 0u; neg += reward < 0 ? 1u : 0u;
     }
-    // Call once at kernel exit, where every lane of the wave is active.  A thread may count at most
-    // 65535 episodes per launch (the host splits longer rollouts).
+    // totals of a whole group at once: `finished` episodes, sum of their rewards and of |reward|
+    // (rewards are -1/0/+1, and only the step that ends an episode can carry one)
+    __device__ __forceinline__ void add_totals(uint32_t finished, int32_t reward_sum, uint32_t nonzero) {
+        fin += finished; pos += (nonzero + (uint32_t)reward_sum) >> 1; neg += (nonzero - (uint32_t)reward_sum) >> 1;
+    }
+    // Call once at kernel exit, where every lane of the wave is active.
     __device__ __forceinline__ void flush(const KernelParams& P) {
-        const uint32_t tot = wave_sum(fp & 0xffffu), pos = wave_sum(fp >> 16), neg = wave_sum(ng);
+        const uint32_t tot = wave_sum(fin), p = wave_sum(pos), n = wave_sum(neg);
         if ((threadIdx.x & 63u) == 0u && tot) {
             unsigned long long* h = slot(P);
             if (!EARLY) { old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2]; }
-            *reinterpret_cast<ulonglong2*>(h) = make_ulonglong2(old01.x + neg, old01.y + (tot - pos - neg));
-            h[2] = old2 + pos;
+            *reinterpret_cast<ulonglong2*>(h) = make_ulonglong2(old01.x + n, old01.y + (tot - p - n));
+            h[2] = old2 + p;
         }
     }
 };
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
     // the episode histogram of single steps is opt-in (SOCCER_F_STEP_STATS): counting, the wave
     // reduction and the slot update cost ~0.5 us of a ~9 us launch
     const bool stats = !LEAN && P.step_stats != 0u;
-    HistAcc<true> hist; hist.fp = 0u; hist.ng = 0u; hist.old01 = make_ulonglong2(0ull, 0ull); hist.old2 = 0ull;
+    HistAcc<true> hist; hist.fin = 0u; hist.pos = 0u; hist.neg = 0u; hist.old01 = make_ulonglong2(0ull, 0ull); hist.old2 = 0ull;
     if (stats) hist.init(P);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
     bool mis = false;
@@ -794,6 +796,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
                                               HistAcc<false>& hist, bool& any_misuse) {
     LaneVec<E> S; S.load(P, i0);
     int32_t ret[E], eps[E];
+    uint32_t nonzero = 0u;                  // number of steps of this thread's lanes that carried a reward
 #pragma unroll
     for (int j = 0; j < E; ++j) { ret[j] = 0; eps[j] = 0; }
     PackB<E> aa, ab; aa.clear(); ab.clear();
@@ -845,8 +848,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
             any_misuse |= lane_step<SLIP>(T, P, S.L[j], a, b, d, R);
             if (DYN) s_now[j] = R.obs;
             o_obs.put(j, R.obs); o_rew.put(j, (uint32_t)R.reward & 0xffu); o_term.put(j, R.term); o_trunc.put(j, R.trunc);
-            ret[j] += R.reward; eps[j] += (int32_t)R.finished;
-            hist.add(R.finished, R.reward);
+            ret[j] += R.reward; eps[j] += (int32_t)R.finished; nonzero += (uint32_t)R.reward & 1u;
         }
         const long long off = (long long)s * IO.out_stride;
         if (IO.obs) o_obs.store(IO.obs + off, i0);
@@ -856,6 +858,12 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         aa = naa; ab = nab;
     }
     S.store(P, i0);
+    {
+        int32_t rsum = 0; uint32_t fsum = 0u;
+#pragma unroll
+        for (int j = 0; j < E; ++j) { rsum += ret[j]; fsum += (uint32_t)eps[j]; }
+        hist.add_totals(fsum, rsum, nonzero);
+    }
     if (IO.return_sum) add_words<E>(IO.return_sum, i0, ret);
     if (IO.episode_count) add_words<E>(IO.episode_count, i0, eps);
 }
