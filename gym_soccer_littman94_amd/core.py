@@ -173,6 +173,15 @@ class SoccerBatch:
                                                           nxt.ctypes.data, rew.ctypes.data, done.ctypes.data))
         return count, prob, nxt, rew, done
 
+    def value_iteration(self, theta, discount_factor, max_iterations=1000000):
+        """Best response of the learner against the handle's fixed policy (single-agent mode), on the device.
+        Returns (pi, V, Q, iterations) like the reference's planners.value_iteration."""
+        V = np.zeros(self.nS, np.float64); Q = np.zeros((self.nS, 5), np.float64); pi = np.zeros(self.nS, np.int32)
+        it = C.c_int32()
+        self._check(self.lib.soccer_value_iteration(self.h, float(theta), float(discount_factor), int(max_iterations),
+                                                    V.ctypes.data, Q.ctypes.data, pi.ctypes.data, C.byref(it)))
+        return pi.astype(np.int64), V, Q, int(it.value)
+
     # -- hot path -------------------------------------------------------------------------------
     def reset(self, mask=None, u_reset=None, obs=None):
         self._check(self.lib.batched_reset(self.h, _ptr(mask), _ptr(u_reset), _ptr(obs)))

@@ -706,6 +706,79 @@ extern "C" int soccer_enumerate_transitions(soccer_handle* h, int32_t* count, do
     return rc;
 }
 
+// Value iteration of the learner's best response on a single-agent handle (reference planners.py:4-18).
+// The (state, learner action) lists are assembled on the host from the device-enumerated transition
+// relation exactly as the reference's constructor builds P[s][a] (:167-293), then one kernel iterates.
+extern "C" int soccer_value_iteration(soccer_handle* h, double theta, double discount_factor, int32_t max_iterations,
+                                      double* V, double* Q, int32_t* pi, int32_t* iterations) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_value_iteration during graph capture");
+    if (!V || !Q || !pi || !iterations) return fail(h, SOCCER_E_INVALID, "all four outputs are required");
+    const bool fixed_a = h->P.policy_a != nullptr, fixed_b = h->P.policy_b != nullptr;
+    if (fixed_a == fixed_b)
+        return fail(h, SOCCER_E_INVALID, "value iteration needs single-agent mode: exactly one side with a fixed policy (soccer_set_policy)");
+    if (max_iterations < 1) return fail(h, SOCCER_E_INVALID, "max_iterations must be >= 1");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const Rules& R = h->rules;
+    const int nS = R.nS;
+    if ((size_t)nS * sizeof(double) > 150 * 1024) return fail(h, SOCCER_E_INVALID, "too many states for the single-workgroup planner");
+    const size_t T = R.lut.size(), keys = T * 25, ent = keys * kMaxOutcomes;
+    std::vector<int32_t> count(keys), nxt(ent); std::vector<double> prob(ent); std::vector<int8_t> rew(ent); std::vector<uint8_t> done(ent);
+    if (int rc = soccer_enumerate_transitions(h, count.data(), prob.data(), nxt.data(), rew.data(), done.data())) return rc;
+    std::vector<int8_t> policy(nS);
+    HIP_TRY(h, hipMemcpy(policy.data(), fixed_a ? h->P.policy_a : h->P.policy_b, (size_t)nS, hipMemcpyDeviceToHost));
+    // P[s][a] in the reference's construction order: goal tuples all map to s = 0 and overwrite each other
+    // (identical lists), live tuples own their index
+    std::vector<long> tuple_of(nS, -1);
+    for (size_t f = 0; f < T; ++f) if (R.kind[f] != 0) tuple_of[R.kind[f] == 2 ? 0 : R.lut[f]] = (long)f;
+    std::vector<int32_t> off((size_t)nS * 5 + 1, 0); std::vector<double> c_prob, c_rew; std::vector<int32_t> c_next; std::vector<uint8_t> c_done;
+    const double sign = fixed_a ? -1.0 : 1.0;                           // learner B sees -r (:243-244)
+    for (int s = 0; s < nS; ++s) for (int a = 0; a < 5; ++a) {
+        const long f = tuple_of[s];
+        if (f < 0) return fail(h, SOCCER_E_INVALID, "internal error: observation index %d has no tuple", s);
+        const int aa = fixed_a ? policy[s] : a, ab = fixed_b ? policy[s] : a;
+        const size_t key = (size_t)f * 25 + aa * 5 + ab;
+        for (int k = 0; k < count[key]; ++k) {
+            const size_t e = key * kMaxOutcomes + k;
+            c_prob.push_back(prob[e]); c_next.push_back(R.kind[nxt[e]] == 2 ? 0 : R.lut[nxt[e]]);
+            c_rew.push_back(sign == 1.0 ? (double)rew[e] : -1.0 * (double)rew[e]); c_done.push_back(done[e]);
+        }
+        off[(size_t)s * 5 + a + 1] = (int32_t)c_prob.size();
+    }
+    ViIO io{};
+    void* bufs[10] = {nullptr};
+    const size_t ne = c_prob.size();
+    const size_t sizes[10] = {off.size() * 4, ne * 8, ne * 4, ne * 8, ne, (size_t)nS * 8, (size_t)nS * 8, (size_t)nS * 40, (size_t)nS * 4, 64};
+    int rc = SOCCER_OK;
+    for (int i = 0; i < 10 && rc == SOCCER_OK; ++i)
+        if (hipMalloc(&bufs[i], sizes[i] ? sizes[i] : 1) != hipSuccess) rc = fail(h, SOCCER_E_NOMEM, "out of device memory for the planner");
+    if (rc == SOCCER_OK) {
+        const void* src[5] = {off.data(), c_prob.data(), c_next.data(), c_rew.data(), c_done.data()};
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipMemcpyAsync(bufs[i], src[i], sizes[i], hipMemcpyHostToDevice, h->stream);
+        io.offset = static_cast<int32_t*>(bufs[0]); io.prob = static_cast<double*>(bufs[1]); io.next = static_cast<int32_t*>(bufs[2]);
+        io.reward = static_cast<double*>(bufs[3]); io.done = static_cast<uint8_t*>(bufs[4]);
+        io.V = static_cast<double*>(bufs[5]); io.newV = static_cast<double*>(bufs[6]); io.Q = static_cast<double*>(bufs[7]);
+        io.pi = static_cast<int32_t*>(bufs[8]); io.iterations = static_cast<int32_t*>(bufs[9]);
+        io.nS = nS; io.max_iterations = max_iterations; io.theta = theta; io.gamma = discount_factor;
+        const size_t smem = (size_t)nS * sizeof(double);
+        if (e == hipSuccess && smem > 48 * 1024)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_iteration_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(value_iteration_kernel, dim3(1), dim3(1024), smem, h->stream, io);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(V, bufs[5], sizes[5], hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(Q, bufs[7], sizes[7], hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(pi, bufs[8], sizes[8], hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(iterations, bufs[9], 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, SOCCER_E_HIP, "value iteration failed: %s", hipGetErrorString(e));
+    }
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    return rc;
+}
+
 // single-agent mode: one side follows a fixed policy looked up by the current observation index
 // (reference :54-56, :187-188).  policy_host NULL clears it.
 extern "C" int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_host, int32_t n_states) {

@@ -956,4 +956,58 @@ __global__ __launch_bounds__(kBlock) void enumerate_kernel(const KernelParams P,
     IO.count[gid] = n;
 }
 
+// =================================================================================================
+// value iteration on the single-agent transition lists (reference gym_soccer/utils/planners.py:4-18)
+// =================================================================================================
+struct ViIO {
+    const int32_t* offset;      // [nS*5 + 1] CSR offsets of the (state, learner action) lists
+    const double* prob;         // per entry, in the reference's list order
+    const int32_t* next;        // observation index of the next state
+    const double* reward;       // learner's reward (+-1, +-0)
+    const uint8_t* done;
+    double* V; double* newV; double* Q; int32_t* pi; int32_t* iterations;   // global outputs / scratch
+    int32_t nS; int32_t max_iterations;
+    double theta, gamma;
+};
+
+// One workgroup runs the whole fixed-point iteration (the problem is 761 x 5 lists; a launch per sweep
+// would be pure launch latency).  Synchronous sweeps, float64, every list summed sequentially in list
+// order with exactly the reference's expression  Q += p * (r + gamma * V[ns] * (not done)),  so the
+// values, the greedy policy and the iteration count are the reference's, bit for bit.
+__global__ __launch_bounds__(1024) void value_iteration_kernel(const ViIO IO) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    double* V = reinterpret_cast<double*>(smem);                 // [nS]
+    __shared__ unsigned long long s_delta;
+    for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) V[s] = 0.0;
+    int cc = 0;
+    for (;;) {
+        if (threadIdx.x == 0) s_delta = 0ull;
+        __syncthreads();
+        double dmax = 0.0;
+        for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) {
+            double best = 0.0; int arg = 0;
+            for (int a = 0; a < 5; ++a) {
+                double q = 0.0;
+                for (int e = IO.offset[s * 5 + a]; e < IO.offset[s * 5 + a + 1]; ++e) {
+                    const double cont = (IO.gamma * V[IO.next[e]]) * (IO.done[e] ? 0.0 : 1.0);
+                    q = q + IO.prob[e] * (IO.reward[e] + cont);
+                }
+                IO.Q[s * 5 + a] = q;
+                if (a == 0 || q > best) { best = q; arg = a; }            // np.argmax: first maximum
+            }
+            IO.newV[s] = best; IO.pi[s] = arg;
+            dmax = fmax(dmax, fabs(V[s] - best));
+        }
+        atomicMax(&s_delta, (unsigned long long)__double_as_longlong(dmax));   // non-negative doubles order as integers
+        __syncthreads();
+        ++cc;
+        const double delta = __longlong_as_double((long long)s_delta);
+        if (delta < IO.theta || cc >= IO.max_iterations) break;           // uniform
+        for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) V[s] = IO.newV[s];
+        __syncthreads();
+    }
+    for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) IO.V[s] = V[s];   // the reference returns the pre-update V
+    if (threadIdx.x == 0) *IO.iterations = cc;
+}
+
 }  // namespace soccer

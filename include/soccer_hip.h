@@ -227,6 +227,14 @@ int soccer_get_tables(const soccer_handle* h, uint16_t* lut, int8_t* goal_value,
  *   done (:235-240). */
 int soccer_enumerate_transitions(soccer_handle* h, int32_t* count, double* prob, int32_t* next_flat,
                                  int8_t* reward, uint8_t* done);
+/* Value iteration of the learner's best response against the fixed side of a single-agent handle (exactly one
+ * policy set): the reference's planner gym_soccer/utils/planners.py:4-18 on the tables above, run on the
+ * device.  Synchronous sweeps until max|V - max_a Q| < theta (or max_iterations); HOST outputs V[n_states]
+ * (the pre-update values, as the reference returns them), Q[n_states*5], pi[n_states] (first maximising
+ * action), iterations.  Float64, every list summed in list order with the reference's expression: the
+ * results are the reference's bit for bit. */
+int soccer_value_iteration(soccer_handle* h, double theta, double discount_factor, int32_t max_iterations,
+                           double* V, double* Q, int32_t* pi, int32_t* iterations);
 /* HOST output: prob[c*3+k] = slip-combination weight c (0: no slip, 1: B slips, 2: A slips,
  * 3: both; :211-222, evaluated left to right in float64) times outcome probability 1, 0.5, 0.25
  * (k = 0,1,2; :326-360).  prob_code values index this table (:241). */

@@ -175,3 +175,52 @@ class Oracle:
         mb = None if mix_b is None else np.ascontiguousarray(mix_b, np.uint16)
         self.L.soc_oracle_sample_actions_mixed(self.n, self.seed, self.lane_offset, self.tick, _p(o), _p(ma), _p(mb), _p(a), _p(b))
         return a, b
+
+
+# -------------------------------------------------------------------------------------------------
+# planners (reference gym_soccer/utils/planners.py:4-18) — restated over the oracle's transition lists
+# -------------------------------------------------------------------------------------------------
+def single_agent_lists(orc, learner, policy):
+    """P[s][a] of a single-agent env as the reference's constructor builds it (:167-293): the fixed side
+    plays policy[s]; learner B's reward is flipped (:243-244); goal tuples all write index 0."""
+    lut, kind, gv, isd, isdp = orc.tables()
+    H, W = orc.H, orc.W
+    P = {}
+    for f in np.flatnonzero(kind != 0).tolist():
+        p_ = f & 1; r = f >> 1
+        yb = r % W; r //= W; xb = r % H; r //= H; ya = r % W; xa = r // W
+        s = 0 if kind[f] == 2 else int(lut[f])
+        P[s] = {}
+        for a in range(5):
+            aa, ab = (a, int(policy[s])) if learner == "player_a" else (int(policy[s]), a)
+            ps, ns, rs, ds = orc.transitions((xa, ya, xb, yb, p_), aa, ab)
+            lst = []
+            for k in range(len(ps)):
+                nf = ((((int(ns[k][0]) * W + int(ns[k][1])) * H + int(ns[k][2])) * W + int(ns[k][3])) << 1) | int(ns[k][4])
+                rr = float(rs[k])
+                if learner == "player_b":
+                    rr = -1 * rr
+                lst.append((float(ps[k]), 0 if kind[nf] == 2 else int(lut[nf]), rr, bool(ds[k])))
+            P[s][a] = lst
+    return P
+
+
+def value_iteration(P, nS, theta=1e-10, discount_factor=0.99, max_iterations=1000000):
+    """planners.py:4-18: synchronous sweeps, python-float accumulation in list order."""
+    V = [0.0] * nS
+    cc = 0
+    while True:
+        cc += 1
+        Q = [[0.0] * 5 for _ in range(nS)]
+        for s in range(nS):
+            for a in range(5):
+                q = 0.0
+                for prob, ns, reward, done in P[s][a]:
+                    q += prob * (reward + discount_factor * V[ns] * (not done))
+                Q[s][a] = q
+        newV = [max(row) for row in Q]
+        if max(abs(V[s] - newV[s]) for s in range(nS)) < theta or cc >= max_iterations:
+            break
+        V = newV
+    Qn = np.array(Q)
+    return np.argmax(Qn, axis=1), np.array(V), Qn, cc

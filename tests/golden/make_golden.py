@@ -24,6 +24,7 @@ What is dumped
                               the real reset()/step(), with the uniforms the
                               env drew recorded alongside
   single_5x4_s{slip}_{agent}.npz  single-agent (fixed-opponent) transition table
+  vi_5x4_s{slip}_{agent}_vs_{opp}.npz  the reference's value_iteration (utils/planners.py) on its own tables
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -273,5 +274,37 @@ def main():
         dump_single_agent(Env, 0.2, learner)
 
 
+
+
+def dump_value_iteration(Env, slip, learner, opponent, tag):
+    """The reference's own planner (gym_soccer/utils/planners.py:4-18) on the reference's own tables:
+    synchronous value iteration of the learner's best response against a fixed opponent policy."""
+    from gym_soccer.utils.planners import value_iteration
+    from gym_soccer.utils.policies import get_random_policy, get_stand_policy
+    policy = get_random_policy(761, 5, seed=0) if opponent == "random" else get_stand_policy(761)
+    kw = {"player_b_policy": policy} if learner == "player_a" else {"player_a_policy": policy}
+    env = Env(width=5, height=4, slip_prob=slip, **kw)
+    t0 = time.time()
+    pi, V, Q, cc = value_iteration(env, theta=1e-10, discount_factor=0.99)
+    out = os.path.join(HERE, "vi_5x4_s%s_%s_vs_%s.npz" % (slip_tag(slip), learner, opponent))
+    np.savez_compressed(out, slip=np.float64(slip), learner=np.bytes_(learner),
+                        policy=np.asarray([policy[s] for s in range(761)], np.int8),
+                        theta=np.float64(1e-10), discount_factor=np.float64(0.99),
+                        pi=np.asarray(pi, np.int64), V=np.asarray(V, np.float64), Q=np.asarray(Q, np.float64),
+                        iterations=np.int64(cc))
+    print("  %s: %d iterations, %.0fs, %d KB" % (os.path.basename(out), cc, time.time() - t0, os.path.getsize(out) // 1024))
+
+
+def main_planners():
+    _install_gym_stand_in()
+    from gym_soccer.envs import SoccerSimultaneousEnv as Env
+    for slip, learner, opp in [(0.2, "player_a", "random"), (0.2, "player_b", "random"), (0.0, "player_a", "stand")]:
+        dump_value_iteration(Env, slip, learner, opp, "")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "planners":
+        main_planners()
+    else:
+        main()
+        main_planners()
