@@ -76,6 +76,15 @@ PROTOTYPES = {
     "soccer_enumerate_transitions": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     "soccer_value_iteration": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.POINTER(C.c_int32)]),
+    "soccer_policy_evaluation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p,
+                                           C.POINTER(C.c_int32)]),
+    "soccer_policy_improvement": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "soccer_policy_iteration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "soccer_policy_eval_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "soccer_modified_policy_iteration": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "soccer_prob_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_double * 12)]),
     "soccer_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_uint64)]),
     "soccer_reset_stats": (C.c_int, [C.c_void_p]),

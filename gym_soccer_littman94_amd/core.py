@@ -173,13 +173,58 @@ class SoccerBatch:
                                                           nxt.ctypes.data, rew.ctypes.data, done.ctypes.data))
         return count, prob, nxt, rew, done
 
-    def value_iteration(self, theta, discount_factor, max_iterations=1000000):
-        """Best response of the learner against the handle's fixed policy (single-agent mode), on the device.
-        Returns (pi, V, Q, iterations) like the reference's planners.value_iteration."""
-        V = np.zeros(self.nS, np.float64); Q = np.zeros((self.nS, 5), np.float64); pi = np.zeros(self.nS, np.int32)
-        it = C.c_int32()
-        self._check(self.lib.soccer_value_iteration(self.h, float(theta), float(discount_factor), int(max_iterations),
+    # -- planners on the device (single-agent mode; reference utils/planners.py) ------------------
+    def _plan_out(self):
+        return (np.zeros(self.nS, np.float64), np.zeros((self.nS, 5), np.float64), np.zeros(self.nS, np.int32), C.c_int32())
+
+    def value_iteration(self, theta, discount_factor, max_sweeps=1000000):
+        """Best response of the learner against the handle's fixed policy.  Returns (pi, V, Q, iterations)
+        like the reference's planners.value_iteration, bit for bit."""
+        V, Q, pi, it = self._plan_out()
+        self._check(self.lib.soccer_value_iteration(self.h, float(theta), float(discount_factor), int(max_sweeps),
                                                     V.ctypes.data, Q.ctypes.data, pi.ctypes.data, C.byref(it)))
+        return pi.astype(np.int64), V, Q, int(it.value)
+
+    def policy_evaluation(self, pi, theta, discount_factor, max_sweeps=1000000):
+        pi = np.ascontiguousarray(np.asarray(pi).reshape(-1), np.int32)
+        assert pi.shape == (self.nS,), "pi must have one action per observation index"
+        V, _, _, it = self._plan_out()
+        self._check(self.lib.soccer_policy_evaluation(self.h, pi.ctypes.data, float(theta), float(discount_factor),
+                                                      int(max_sweeps), V.ctypes.data, C.byref(it)))
+        return V, int(it.value)
+
+    def policy_improvement(self, V, discount_factor):
+        V = np.ascontiguousarray(np.asarray(V).reshape(-1), np.float64)
+        assert V.shape == (self.nS,), "V must have one value per observation index"
+        _, Q, pi, _ = self._plan_out()
+        self._check(self.lib.soccer_policy_improvement(self.h, V.ctypes.data, float(discount_factor), Q.ctypes.data, pi.ctypes.data))
+        return pi.astype(np.int64), Q
+
+    def policy_iteration(self, pi0, theta, discount_factor, max_sweeps=1000000):
+        pi0 = np.ascontiguousarray(np.asarray(pi0).reshape(-1), np.int32)
+        assert pi0.shape == (self.nS,), "the initial policy must have one action per observation index"
+        V, Q, pi, it = self._plan_out()
+        self._check(self.lib.soccer_policy_iteration(self.h, pi0.ctypes.data, float(theta), float(discount_factor),
+                                                     int(max_sweeps), V.ctypes.data, Q.ctypes.data, pi.ctypes.data, C.byref(it)))
+        return pi.astype(np.int64), V, Q, int(it.value)
+
+    def policy_eval_dense(self, policy, theta, discount_factor, k=10000000, init=None, max_sweeps=10000000):
+        policy = np.ascontiguousarray(policy, np.float64)
+        assert policy.shape == (self.nS, 5), "policy must be [nS, nA]"
+        init_p = None
+        if init is not None:
+            init = np.ascontiguousarray(np.asarray(init).reshape(-1), np.float64)
+            assert init.shape == (self.nS,)
+            init_p = init.ctypes.data
+        V, _, _, it = self._plan_out()
+        self._check(self.lib.soccer_policy_eval_dense(self.h, policy.ctypes.data, int(min(k, 2**31 - 1)), float(theta),
+                                                      float(discount_factor), int(max_sweeps), init_p, V.ctypes.data, C.byref(it)))
+        return V, int(it.value)
+
+    def modified_policy_iteration(self, k, theta, discount_factor, max_sweeps=10000000):
+        V, Q, pi, it = self._plan_out()
+        self._check(self.lib.soccer_modified_policy_iteration(self.h, int(min(k, 2**31 - 1)), float(theta), float(discount_factor),
+                                                              int(max_sweeps), V.ctypes.data, Q.ctypes.data, pi.ctypes.data, C.byref(it)))
         return pi.astype(np.int64), V, Q, int(it.value)
 
     # -- hot path -------------------------------------------------------------------------------

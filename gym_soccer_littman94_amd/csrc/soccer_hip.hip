@@ -55,6 +55,9 @@ struct soccer_handle {
     uint64_t capture_ticks = 0;
     int capture_calls = 0;
     int capture_start_slot = 0;
+    PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
+    std::vector<void*> plan_bufs;
+    bool plan_ready = false;
     std::string err;
 };
 
@@ -96,6 +99,7 @@ static void free_handle(soccer_handle* h) {
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
     void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -706,77 +710,180 @@ extern "C" int soccer_enumerate_transitions(soccer_handle* h, int32_t* count, do
     return rc;
 }
 
-// Value iteration of the learner's best response on a single-agent handle (reference planners.py:4-18).
-// The (state, learner action) lists are assembled on the host from the device-enumerated transition
-// relation exactly as the reference's constructor builds P[s][a] (:167-293), then one kernel iterates.
-extern "C" int soccer_value_iteration(soccer_handle* h, double theta, double discount_factor, int32_t max_iterations,
-                                      double* V, double* Q, int32_t* pi, int32_t* iterations) {
-    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
-    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_value_iteration during graph capture");
-    if (!V || !Q || !pi || !iterations) return fail(h, SOCCER_E_INVALID, "all four outputs are required");
+// ------------------------------------------------------------------------------------------------
+// planners (reference gym_soccer/utils/planners.py).  The (state, learner action) lists are assembled on
+// the host from the device-enumerated transition relation exactly as the reference's constructor builds
+// P[s][a], Pmat and Rmat (:167-293), cached on the handle until the policy changes, and one
+// single-workgroup kernel runs the whole planner.
+static void drop_plan(soccer_handle* h) {
+    for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
+    h->plan_bufs.clear(); h->plan_ready = false;
+}
+
+template <class T>
+static int plan_upload(soccer_handle* h, const std::vector<T>& v, const T** out) {
+    void* d = nullptr;
+    const size_t bytes = v.size() * sizeof(T);
+    if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return fail(h, SOCCER_E_NOMEM, "out of device memory for the planner lists");
+    h->plan_bufs.push_back(d);
+    if (bytes && hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(h, SOCCER_E_HIP, "planner list upload failed");
+    *out = static_cast<const T*>(d);
+    return SOCCER_OK;
+}
+
+static int build_plan(soccer_handle* h) {
+    if (h->plan_ready) return SOCCER_OK;
     const bool fixed_a = h->P.policy_a != nullptr, fixed_b = h->P.policy_b != nullptr;
     if (fixed_a == fixed_b)
-        return fail(h, SOCCER_E_INVALID, "value iteration needs single-agent mode: exactly one side with a fixed policy (soccer_set_policy)");
-    if (max_iterations < 1) return fail(h, SOCCER_E_INVALID, "max_iterations must be >= 1");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+        return fail(h, SOCCER_E_INVALID, "planners need single-agent mode: exactly one side with a fixed policy (soccer_set_policy)");
     const Rules& R = h->rules;
     const int nS = R.nS;
-    if ((size_t)nS * sizeof(double) > 150 * 1024) return fail(h, SOCCER_E_INVALID, "too many states for the single-workgroup planner");
+    if ((size_t)nS * sizeof(double) > 150 * 1024) return fail(h, SOCCER_E_INVALID, "too many states (%d) for the single-workgroup planner", nS);
     const size_t T = R.lut.size(), keys = T * 25, ent = keys * kMaxOutcomes;
     std::vector<int32_t> count(keys), nxt(ent); std::vector<double> prob(ent); std::vector<int8_t> rew(ent); std::vector<uint8_t> done(ent);
     if (int rc = soccer_enumerate_transitions(h, count.data(), prob.data(), nxt.data(), rew.data(), done.data())) return rc;
     std::vector<int8_t> policy(nS);
     HIP_TRY(h, hipMemcpy(policy.data(), fixed_a ? h->P.policy_a : h->P.policy_b, (size_t)nS, hipMemcpyDeviceToHost));
-    // P[s][a] in the reference's construction order: goal tuples all map to s = 0 and overwrite each other
-    // (identical lists), live tuples own their index
+    auto obs_of = [&](size_t f) { return R.kind[f] == 2 ? 0 : (int)R.lut[f]; };
+    const bool flip = fixed_a;                                          // learner B sees -r (:243-244)
+    // P[s][a]: goal tuples all write index 0 and overwrite each other (identical lists), live tuples own theirs
     std::vector<long> tuple_of(nS, -1);
-    for (size_t f = 0; f < T; ++f) if (R.kind[f] != 0) tuple_of[R.kind[f] == 2 ? 0 : R.lut[f]] = (long)f;
-    std::vector<int32_t> off((size_t)nS * 5 + 1, 0); std::vector<double> c_prob, c_rew; std::vector<int32_t> c_next; std::vector<uint8_t> c_done;
-    const double sign = fixed_a ? -1.0 : 1.0;                           // learner B sees -r (:243-244)
+    for (size_t f = 0; f < T; ++f) if (R.kind[f] != 0) tuple_of[obs_of(f)] = (long)f;
+    std::vector<int32_t> off((size_t)nS * 5 + 1, 0), c_next; std::vector<double> c_prob, c_rew; std::vector<uint8_t> c_done;
     for (int s = 0; s < nS; ++s) for (int a = 0; a < 5; ++a) {
         const long f = tuple_of[s];
         if (f < 0) return fail(h, SOCCER_E_INVALID, "internal error: observation index %d has no tuple", s);
-        const int aa = fixed_a ? policy[s] : a, ab = fixed_b ? policy[s] : a;
-        const size_t key = (size_t)f * 25 + aa * 5 + ab;
+        const size_t key = (size_t)f * 25 + (fixed_a ? policy[s] : a) * 5 + (fixed_b ? policy[s] : a);
         for (int k = 0; k < count[key]; ++k) {
             const size_t e = key * kMaxOutcomes + k;
-            c_prob.push_back(prob[e]); c_next.push_back(R.kind[nxt[e]] == 2 ? 0 : R.lut[nxt[e]]);
-            c_rew.push_back(sign == 1.0 ? (double)rew[e] : -1.0 * (double)rew[e]); c_done.push_back(done[e]);
+            c_prob.push_back(prob[e]); c_next.push_back(obs_of((size_t)nxt[e]));
+            c_rew.push_back(flip ? -1.0 * (double)rew[e] : (double)rew[e]); c_done.push_back(done[e]);
         }
         off[(size_t)s * 5 + a + 1] = (int32_t)c_prob.size();
     }
-    ViIO io{};
-    void* bufs[10] = {nullptr};
-    const size_t ne = c_prob.size();
-    const size_t sizes[10] = {off.size() * 4, ne * 8, ne * 4, ne * 8, ne, (size_t)nS * 8, (size_t)nS * 8, (size_t)nS * 40, (size_t)nS * 4, 64};
-    int rc = SOCCER_OK;
-    for (int i = 0; i < 10 && rc == SOCCER_OK; ++i)
-        if (hipMalloc(&bufs[i], sizes[i] ? sizes[i] : 1) != hipSuccess) rc = fail(h, SOCCER_E_NOMEM, "out of device memory for the planner");
-    if (rc == SOCCER_OK) {
-        const void* src[5] = {off.data(), c_prob.data(), c_next.data(), c_rew.data(), c_done.data()};
-        hipError_t e = hipSuccess;
-        for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipMemcpyAsync(bufs[i], src[i], sizes[i], hipMemcpyHostToDevice, h->stream);
-        io.offset = static_cast<int32_t*>(bufs[0]); io.prob = static_cast<double*>(bufs[1]); io.next = static_cast<int32_t*>(bufs[2]);
-        io.reward = static_cast<double*>(bufs[3]); io.done = static_cast<uint8_t*>(bufs[4]);
-        io.V = static_cast<double*>(bufs[5]); io.newV = static_cast<double*>(bufs[6]); io.Q = static_cast<double*>(bufs[7]);
-        io.pi = static_cast<int32_t*>(bufs[8]); io.iterations = static_cast<int32_t*>(bufs[9]);
-        io.nS = nS; io.max_iterations = max_iterations; io.theta = theta; io.gamma = discount_factor;
-        const size_t smem = (size_t)nS * sizeof(double);
-        if (e == hipSuccess && smem > 48 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_iteration_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(value_iteration_kernel, dim3(1), dim3(1024), smem, h->stream, io);
-            e = hipGetLastError();
+    // Pmat[s][ns][a] += p and Rmat[s][a] (= 0, then += p * r) in the constructor's tuple order (:280-291):
+    // index 0 accumulates one unit of probability per goal tuple, its Rmat is the last goal tuple's (0)
+    std::vector<std::vector<double>> row((size_t)nS * 5);               // dense rows only for touched (s, a)
+    std::vector<double> Rm((size_t)nS * 5, 0.0);
+    for (size_t f = 0; f < T; ++f) {
+        if (R.kind[f] == 0) continue;
+        const int s = obs_of(f);
+        for (int a = 0; a < 5; ++a) {
+            const size_t key = f * 25 + (fixed_a ? policy[s] : a) * 5 + (fixed_b ? policy[s] : a);
+            std::vector<double>& r = row[(size_t)s * 5 + a];
+            if (r.empty()) r.assign(nS, 0.0);
+            double acc = 0.0;
+            for (int k = 0; k < count[key]; ++k) {
+                const size_t e = key * kMaxOutcomes + k;
+                const double rr = flip ? -1.0 * (double)rew[e] : (double)rew[e];
+                r[obs_of((size_t)nxt[e])] += prob[e];
+                acc = acc + prob[e] * rr;
+            }
+            Rm[(size_t)s * 5 + a] = acc;
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(V, bufs[5], sizes[5], hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(Q, bufs[7], sizes[7], hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(pi, bufs[8], sizes[8], hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(iterations, bufs[9], 4, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) rc = fail(h, SOCCER_E_HIP, "value iteration failed: %s", hipGetErrorString(e));
     }
-    for (void* b : bufs) if (b) (void)hipFree(b);
-    return rc;
+    std::vector<int32_t> m_off((size_t)nS * 5 + 1, 0), m_next; std::vector<double> m_prob;
+    for (size_t q = 0; q < (size_t)nS * 5; ++q) {
+        for (int ns = 0; ns < nS; ++ns) if (row[q][ns] != 0.0) { m_next.push_back(ns); m_prob.push_back(row[q][ns]); }
+        m_off[q + 1] = (int32_t)m_next.size();
+        std::vector<double>().swap(row[q]);
+    }
+    PlanIO& io = h->plan;
+    io = PlanIO{};
+    int rc = plan_upload(h, off, &io.offset);
+    if (!rc) rc = plan_upload(h, c_prob, &io.prob);
+    if (!rc) rc = plan_upload(h, c_next, &io.next);
+    if (!rc) rc = plan_upload(h, c_rew, &io.reward);
+    if (!rc) rc = plan_upload(h, c_done, &io.done);
+    if (!rc) rc = plan_upload(h, m_off, &io.m_offset);
+    if (!rc) rc = plan_upload(h, m_prob, &io.m_prob);
+    if (!rc) rc = plan_upload(h, m_next, &io.m_next);
+    if (!rc) rc = plan_upload(h, Rm, &io.m_R);
+    const std::vector<double> zV(nS, 0.0), zQ((size_t)nS * 5, 0.0); const std::vector<int32_t> zpi(nS, 0), zc(16, 0);
+    const double* cV = nullptr; const double* cN = nullptr; const double* cQ = nullptr; const int32_t* cpi = nullptr; const int32_t* cc = nullptr;
+    if (!rc) rc = plan_upload(h, zV, &cV);
+    if (!rc) rc = plan_upload(h, zV, &cN);
+    if (!rc) rc = plan_upload(h, zQ, &cQ);
+    if (!rc) rc = plan_upload(h, zpi, &cpi);
+    if (!rc) rc = plan_upload(h, zc, &cc);
+    if (rc) { drop_plan(h); return rc; }
+    io.V = const_cast<double*>(cV); io.newV = const_cast<double*>(cN); io.Q = const_cast<double*>(cQ);
+    io.pi = const_cast<int32_t*>(cpi); io.counters = const_cast<int32_t*>(cc);
+    io.nS = nS;
+    const size_t smem = (size_t)nS * sizeof(double);
+    if (smem > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&planner_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    h->plan_ready = true;
+    return SOCCER_OK;
+}
+
+// runs one planner; inputs pi_in / V_in and every output are HOST pointers (any output may be NULL)
+static int run_plan(soccer_handle* h, const char* what, int mode, double theta, double gamma, int32_t max_sweeps, int32_t k,
+                    const int32_t* pi_in, const double* V_in, const double* Q_in, double* V, double* Q, int32_t* pi, int32_t* iterations) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "%s during graph capture", what);
+    if (max_sweeps < 1) return fail(h, SOCCER_E_INVALID, "max_sweeps must be >= 1");
+    if (!(gamma >= 0.0 && gamma <= 1.0)) return fail(h, SOCCER_E_INVALID, "discount_factor must be in [0, 1]");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (int rc = build_plan(h)) return rc;
+    PlanIO io = h->plan;
+    const int nS = io.nS;
+    if (pi_in) {
+        for (int s = 0; s < nS; ++s) if (pi_in[s] < 0 || pi_in[s] > 4) return fail(h, SOCCER_E_INVALID, "pi[%d] = %d is not an action", s, pi_in[s]);
+        HIP_TRY(h, hipMemcpyAsync(io.pi, pi_in, (size_t)nS * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (V_in) HIP_TRY(h, hipMemcpyAsync(io.V, V_in, (size_t)nS * 8, hipMemcpyHostToDevice, h->stream));
+    else if (mode == kPlanEvalDense) HIP_TRY(h, hipMemsetAsync(io.V, 0, (size_t)nS * 8, h->stream));
+    if (Q_in) HIP_TRY(h, hipMemcpyAsync(io.Q, Q_in, (size_t)nS * 40, hipMemcpyHostToDevice, h->stream));
+    io.mode = mode; io.theta = theta; io.gamma = gamma; io.max_sweeps = max_sweeps; io.k = k;
+    io.threshold = (theta * (1 - gamma)) / (2 * gamma);                  // planners.py:75
+    hipLaunchKernelGGL(planner_kernel, dim3(1), dim3(1024), (size_t)nS * sizeof(double), h->stream, io);
+    HIP_TRY(h, hipGetLastError());
+    int32_t counters[4] = {0, 0, 0, 0};
+    if (V) HIP_TRY(h, hipMemcpyAsync(V, io.V, (size_t)nS * 8, hipMemcpyDeviceToHost, h->stream));
+    if (Q) HIP_TRY(h, hipMemcpyAsync(Q, io.Q, (size_t)nS * 40, hipMemcpyDeviceToHost, h->stream));
+    if (pi) HIP_TRY(h, hipMemcpyAsync(pi, io.pi, (size_t)nS * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(counters, io.counters, 12, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (iterations) *iterations = counters[0];
+    if (counters[2]) return fail(h, SOCCER_E_STATE, "%s stopped after max_sweeps = %d sweeps without converging", what, max_sweeps);
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_value_iteration(soccer_handle* h, double theta, double discount_factor, int32_t max_sweeps,
+                                      double* V, double* Q, int32_t* pi, int32_t* iterations) {
+    return run_plan(h, "soccer_value_iteration", kPlanVI, theta, discount_factor, max_sweeps, 0, nullptr, nullptr, nullptr, V, Q, pi, iterations);
+}
+
+extern "C" int soccer_policy_evaluation(soccer_handle* h, const int32_t* pi, double theta, double discount_factor,
+                                        int32_t max_sweeps, double* V, int32_t* sweeps) {
+    if (h && !pi) return fail(h, SOCCER_E_INVALID, "pi is NULL");
+    return run_plan(h, "soccer_policy_evaluation", kPlanEval, theta, discount_factor, max_sweeps, 0, pi, nullptr, nullptr, V, nullptr, nullptr, sweeps);
+}
+
+extern "C" int soccer_policy_improvement(soccer_handle* h, const double* V, double discount_factor, double* Q, int32_t* new_pi) {
+    if (h && !V) return fail(h, SOCCER_E_INVALID, "V is NULL");
+    return run_plan(h, "soccer_policy_improvement", kPlanImprove, 0.0, discount_factor, 1, 0, nullptr, V, nullptr, nullptr, Q, new_pi, nullptr);
+}
+
+extern "C" int soccer_policy_iteration(soccer_handle* h, const int32_t* pi0, double theta, double discount_factor,
+                                       int32_t max_sweeps, double* V, double* Q, int32_t* pi, int32_t* iterations) {
+    if (h && !pi0) return fail(h, SOCCER_E_INVALID, "pi0 (the initial policy) is NULL");
+    return run_plan(h, "soccer_policy_iteration", kPlanPI, theta, discount_factor, max_sweeps, 0, pi0, nullptr, nullptr, V, Q, pi, iterations);
+}
+
+extern "C" int soccer_modified_policy_iteration(soccer_handle* h, int32_t k, double theta, double discount_factor,
+                                                int32_t max_sweeps, double* V, double* Q, int32_t* pi, int32_t* iterations) {
+    if (h && k < 1) return fail(h, SOCCER_E_INVALID, "k must be >= 1");
+    if (h && !(discount_factor > 0.0)) return fail(h, SOCCER_E_INVALID, "discount_factor must be > 0 for the stopping threshold");
+    return run_plan(h, "soccer_modified_policy_iteration", kPlanMPI, theta, discount_factor, max_sweeps, k, nullptr, nullptr, nullptr, V, Q, pi, iterations);
+}
+
+extern "C" int soccer_policy_eval_dense(soccer_handle* h, const double* policy, int32_t k, double theta, double discount_factor,
+                                        int32_t max_sweeps, const double* init, double* v, int32_t* sweeps) {
+    if (h && !policy) return fail(h, SOCCER_E_INVALID, "policy is NULL");
+    if (h && k < 1) return fail(h, SOCCER_E_INVALID, "k must be >= 1");
+    return run_plan(h, "soccer_policy_eval_dense", kPlanEvalDense, theta, discount_factor, max_sweeps, k, nullptr, init, policy, v, nullptr, nullptr, sweeps);
 }
 
 // single-agent mode: one side follows a fixed policy looked up by the current observation index
@@ -788,6 +895,7 @@ extern "C" int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t*
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int8_t** slot = player == 0 ? &h->P.policy_a : &h->P.policy_b;
+    drop_plan(h);
     if (!policy_host) { *slot = nullptr; return SOCCER_OK; }
     if (n_states != h->rules.nS) return fail(h, SOCCER_E_INVALID, "policy must have one action per observation index (%d)", h->rules.nS);
     if ((player == 0 ? h->P.policy_b : h->P.policy_a) != nullptr)

@@ -957,57 +957,205 @@ __global__ __launch_bounds__(kBlock) void enumerate_kernel(const KernelParams P,
 }
 
 // =================================================================================================
-// value iteration on the single-agent transition lists (reference gym_soccer/utils/planners.py:4-18)
+// planners on the single-agent transition lists (reference gym_soccer/utils/planners.py:4-87)
 // =================================================================================================
-struct ViIO {
-    const int32_t* offset;      // [nS*5 + 1] CSR offsets of the (state, learner action) lists
-    const double* prob;         // per entry, in the reference's list order
+enum PlanMode : int32_t { kPlanVI = 0, kPlanEval = 1, kPlanImprove = 2, kPlanPI = 3, kPlanMPI = 4, kPlanEvalDense = 5 };
+
+struct PlanIO {
+    // P[s][a] lists in the reference's order (:167-293), CSR by (state, learner action)
+    const int32_t* offset;      // [nS*5 + 1]
+    const double* prob;
     const int32_t* next;        // observation index of the next state
     const double* reward;       // learner's reward (+-1, +-0)
     const uint8_t* done;
-    double* V; double* newV; double* Q; int32_t* pi; int32_t* iterations;   // global outputs / scratch
-    int32_t nS; int32_t max_iterations;
-    double theta, gamma;
+    // rows of Pmat / Rmat (:280-291): per (state, action) the next states in ascending index with their
+    // accumulated probability (the dense dot's order), and the expected reward
+    const int32_t* m_offset; const double* m_prob; const int32_t* m_next; const double* m_R;
+    double* V; double* newV; double* Q; int32_t* pi;
+    int32_t* counters;          // [0] outer iterations, [1] sweeps, [2] 1 = stopped by max_sweeps
+    int32_t nS, mode, max_sweeps, k;
+    double theta, gamma, threshold;
 };
 
-// One workgroup runs the whole fixed-point iteration (the problem is 761 x 5 lists; a launch per sweep
-// would be pure launch latency).  Synchronous sweeps, float64, every list summed sequentially in list
-// order with exactly the reference's expression  Q += p * (r + gamma * V[ns] * (not done)),  so the
-// values, the greedy policy and the iteration count are the reference's, bit for bit.
-__global__ __launch_bounds__(1024) void value_iteration_kernel(const ViIO IO) {
+// Q += prob * (reward + discount_factor * V[next_state] * (not done)), summed in list order (planners.py:12,28,39)
+__device__ __forceinline__ double list_backup(const PlanIO& IO, const double* V, int s, int a) {
+    double q = 0.0;
+    for (int e = IO.offset[s * 5 + a]; e < IO.offset[s * 5 + a + 1]; ++e) {
+        const double cont = (IO.gamma * V[IO.next[e]]) * (IO.done[e] ? 0.0 : 1.0);
+        q = q + IO.prob[e] * (IO.reward[e] + cont);
+    }
+    return q;
+}
+
+// Rmat[s, a] + discount_factor * dot(Pmat[s, :, a], v)   (planners.py:62-65, :80)
+__device__ __forceinline__ double dense_backup(const PlanIO& IO, const double* V, int s, int a) {
+    double acc = 0.0;
+    for (int e = IO.m_offset[s * 5 + a]; e < IO.m_offset[s * 5 + a + 1]; ++e) acc = acc + IO.m_prob[e] * V[IO.m_next[e]];
+    return IO.m_R[s * 5 + a] + IO.gamma * acc;
+}
+
+// maximum of a non-negative double over the workgroup (such doubles order like their bit patterns)
+__device__ __forceinline__ double block_max(double d, unsigned long long* slot) {
+    if (threadIdx.x == 0) *slot = 0ull;
+    __syncthreads();
+    atomicMax(slot, (unsigned long long)__double_as_longlong(d));
+    __syncthreads();
+    const double r = __longlong_as_double((long long)*slot);
+    __syncthreads();
+    return r;
+}
+
+// One workgroup runs a whole planner: the problem is nS x 5 short lists, a launch per sweep would be pure
+// launch latency.  Synchronous sweeps in float64 with V in LDS; the list-based planners (value iteration,
+// policy evaluation / improvement / iteration) evaluate exactly the reference's expressions in the
+// reference's order, so values, greedy policies and iteration counts are the reference's bit for bit;
+// modified policy iteration follows the reference's dense Pmat/Rmat algebra with a sequential dot (numpy's
+// BLAS dot associates differently: equal to ~1e-15 relative, see tests/test_planner.py).
+__global__ __launch_bounds__(1024) void planner_kernel(const PlanIO IO) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     double* V = reinterpret_cast<double*>(smem);                 // [nS]
-    __shared__ unsigned long long s_delta;
-    for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) V[s] = 0.0;
-    int cc = 0;
-    for (;;) {
-        if (threadIdx.x == 0) s_delta = 0ull;
-        __syncthreads();
+    __shared__ unsigned long long s_slot;
+    const int nS = IO.nS, tid = threadIdx.x, nt = blockDim.x;
+    int outer = 0, sweeps = 0, capped = 0;
+
+    // greedy step over the lists: Q, first maximising action; returns max |V - max_a Q| over own states
+    auto greedy_lists = [&](bool* changed) {
         double dmax = 0.0;
-        for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) {
+        for (int s = tid; s < nS; s += nt) {
             double best = 0.0; int arg = 0;
             for (int a = 0; a < 5; ++a) {
-                double q = 0.0;
-                for (int e = IO.offset[s * 5 + a]; e < IO.offset[s * 5 + a + 1]; ++e) {
-                    const double cont = (IO.gamma * V[IO.next[e]]) * (IO.done[e] ? 0.0 : 1.0);
-                    q = q + IO.prob[e] * (IO.reward[e] + cont);
-                }
+                const double q = list_backup(IO, V, s, a);
                 IO.Q[s * 5 + a] = q;
                 if (a == 0 || q > best) { best = q; arg = a; }            // np.argmax: first maximum
             }
-            IO.newV[s] = best; IO.pi[s] = arg;
+            IO.newV[s] = best;
+            if (changed && IO.pi[s] != arg) *changed = true;
+            IO.pi[s] = arg;
             dmax = fmax(dmax, fabs(V[s] - best));
         }
-        atomicMax(&s_delta, (unsigned long long)__double_as_longlong(dmax));   // non-negative doubles order as integers
+        return dmax;
+    };
+    // policy_evaluation (planners.py:20-31) of IO.pi from zeros; leaves the result in IO.newV
+    auto evaluate = [&]() {
+        for (int s = tid; s < nS; s += nt) V[s] = 0.0;
         __syncthreads();
-        ++cc;
-        const double delta = __longlong_as_double((long long)s_delta);
-        if (delta < IO.theta || cc >= IO.max_iterations) break;           // uniform
-        for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) V[s] = IO.newV[s];
+        for (;;) {
+            double dmax = 0.0;
+            for (int s = tid; s < nS; s += nt) {
+                const double v = list_backup(IO, V, s, IO.pi[s]);
+                IO.newV[s] = v;
+                dmax = fmax(dmax, fabs(V[s] - v));
+            }
+            const double delta = block_max(dmax, &s_slot);
+            ++sweeps;
+            if (delta < IO.theta) break;
+            if (sweeps >= IO.max_sweeps) { capped = 1; break; }
+            for (int s = tid; s < nS; s += nt) V[s] = IO.newV[s];
+            __syncthreads();
+        }
+    };
+
+    if (IO.mode == kPlanVI) {                                   // planners.py:4-18
+        for (int s = tid; s < nS; s += nt) V[s] = 0.0;
         __syncthreads();
+        for (;;) {
+            const double delta = block_max(greedy_lists(nullptr), &s_slot);
+            ++outer; ++sweeps;
+            if (delta < IO.theta) break;
+            if (sweeps >= IO.max_sweeps) { capped = 1; break; }
+            for (int s = tid; s < nS; s += nt) V[s] = IO.newV[s];
+            __syncthreads();
+        }
+        for (int s = tid; s < nS; s += nt) IO.V[s] = V[s];       // the reference returns the pre-update V
+    } else if (IO.mode == kPlanEval) {                          // planners.py:20-31
+        evaluate();
+        outer = sweeps;
+        for (int s = tid; s < nS; s += nt) IO.V[s] = IO.newV[s];
+    } else if (IO.mode == kPlanImprove) {                       // planners.py:33-41
+        for (int s = tid; s < nS; s += nt) V[s] = IO.V[s];
+        __syncthreads();
+        (void)greedy_lists(nullptr);
+        outer = 1;
+    } else if (IO.mode == kPlanPI) {                            // planners.py:43-53
+        for (;;) {
+            evaluate();
+            __syncthreads();
+            for (int s = tid; s < nS; s += nt) { V[s] = IO.newV[s]; IO.V[s] = IO.newV[s]; }
+            __syncthreads();
+            bool changed = false;
+            (void)greedy_lists(&changed);
+            ++outer;
+            const double any = block_max(changed ? 1.0 : 0.0, &s_slot);
+            if (any == 0.0 || capped) break;
+        }
+    } else if (IO.mode == kPlanEvalDense) {                     // policy_eval, planners.py:55-70 (policy[s, a] in IO.Q)
+        for (int s = tid; s < nS; s += nt) V[s] = IO.V[s];
+        __syncthreads();
+        for (int i = 0; i < IO.k; ++i) {
+            double d2 = 0.0;
+            for (int s = tid; s < nS; s += nt) {
+                double r_pi = 0.0, p_pi = 0.0;
+                for (int a = 0; a < 5; ++a) {
+                    const double w = IO.Q[s * 5 + a];
+                    double acc = 0.0;
+                    for (int e = IO.m_offset[s * 5 + a]; e < IO.m_offset[s * 5 + a + 1]; ++e) acc = acc + IO.m_prob[e] * V[IO.m_next[e]];
+                    r_pi = r_pi + w * IO.m_R[s * 5 + a];
+                    p_pi = p_pi + acc * w;
+                }
+                const double v = r_pi + IO.gamma * p_pi;
+                IO.newV[s] = v;
+                d2 = fmax(d2, fabs(v - V[s]));
+            }
+            const double delta = block_max(d2, &s_slot);
+            for (int s = tid; s < nS; s += nt) V[s] = IO.newV[s];
+            __syncthreads();
+            ++sweeps;
+            if (delta < IO.theta) break;
+            if (sweeps >= IO.max_sweeps) { capped = 1; break; }
+        }
+        outer = sweeps;
+        for (int s = tid; s < nS; s += nt) IO.V[s] = V[s];
+    } else {                                                    // modified_policy_iteration, planners.py:73-87
+        for (int s = tid; s < nS; s += nt) V[s] = 0.0;
+        __syncthreads();
+        for (;;) {
+            double dmax = 0.0;
+            for (int s = tid; s < nS; s += nt) {
+                double best = 0.0; int arg = 0;
+                for (int a = 0; a < 5; ++a) {
+                    const double q = dense_backup(IO, V, s, a);
+                    IO.Q[s * 5 + a] = q;
+                    if (a == 0 || q > best) { best = q; arg = a; }
+                }
+                IO.newV[s] = best; IO.pi[s] = arg;
+                dmax = fmax(dmax, fabs(V[s] - best));
+            }
+            const double gap = block_max(dmax, &s_slot);
+            ++sweeps;
+            if (gap <= IO.threshold) break;                       // returns greedy_v, q, counter (:83-84)
+            if (sweeps >= IO.max_sweeps) { capped = 1; break; }
+            for (int s = tid; s < nS; s += nt) V[s] = IO.newV[s];  // policy_eval(init = greedy_v), :55-70
+            __syncthreads();
+            for (int i = 0; i < IO.k; ++i) {
+                double d2 = 0.0;
+                for (int s = tid; s < nS; s += nt) {
+                    const double v = dense_backup(IO, V, s, IO.pi[s]);
+                    IO.newV[s] = v;
+                    d2 = fmax(d2, fabs(v - V[s]));
+                }
+                const double delta = block_max(d2, &s_slot);
+                for (int s = tid; s < nS; s += nt) V[s] = IO.newV[s];
+                __syncthreads();
+                ++sweeps;
+                if (delta < IO.theta) break;
+                if (sweeps >= IO.max_sweeps) { capped = 1; break; }
+            }
+            ++outer;
+            if (capped) break;
+        }
+        for (int s = tid; s < nS; s += nt) IO.V[s] = IO.newV[s];
     }
-    for (int s = threadIdx.x; s < IO.nS; s += blockDim.x) IO.V[s] = V[s];   // the reference returns the pre-update V
-    if (threadIdx.x == 0) *IO.iterations = cc;
+    if (tid == 0) { IO.counters[0] = outer; IO.counters[1] = sweeps; IO.counters[2] = capped; }
 }
 
 }  // namespace soccer

@@ -227,14 +227,39 @@ int soccer_get_tables(const soccer_handle* h, uint16_t* lut, int8_t* goal_value,
  *   done (:235-240). */
 int soccer_enumerate_transitions(soccer_handle* h, int32_t* count, double* prob, int32_t* next_flat,
                                  int8_t* reward, uint8_t* done);
-/* Value iteration of the learner's best response against the fixed side of a single-agent handle (exactly one
- * policy set): the reference's planner gym_soccer/utils/planners.py:4-18 on the tables above, run on the
- * device.  Synchronous sweeps until max|V - max_a Q| < theta (or max_iterations); HOST outputs V[n_states]
- * (the pre-update values, as the reference returns them), Q[n_states*5], pi[n_states] (first maximising
- * action), iterations.  Float64, every list summed in list order with the reference's expression: the
- * results are the reference's bit for bit. */
-int soccer_value_iteration(soccer_handle* h, double theta, double discount_factor, int32_t max_iterations,
+/* ---- planners (reference gym_soccer/utils/planners.py) ---------------------------------- */
+/* All of them need a single-agent handle (exactly one side has a policy: soccer_set_policy) and work on the
+ * learner's tables P[s][a] / Pmat / Rmat exactly as the reference's constructor builds them (:167-293), here
+ * assembled from soccer_enumerate_transitions and cached on the handle until the policy changes.  One
+ * single-workgroup kernel runs a whole planner; float64 throughout.  Inputs and outputs are HOST arrays
+ * (V[n_states], Q[n_states*5], pi[n_states] int32); any output may be NULL.  max_sweeps bounds the total
+ * number of sweeps over the state space (SOCCER_E_STATE if it is reached; the outputs hold the last iterate).
+ *
+ * The list-based planners evaluate  Q[s][a] += prob * (reward + discount_factor * V[next] * (not done))  in
+ * list order like the reference: values, greedy policies and iteration counts are the reference's BIT FOR BIT.
+ *   soccer_value_iteration     planners.py:4-18   sweeps until max|V - max_a Q| < theta; V is the pre-update
+ *                                                 iterate (as the reference returns it), pi the first argmax
+ *   soccer_policy_evaluation   planners.py:20-31  V of the deterministic policy pi, from zeros
+ *   soccer_policy_improvement  planners.py:33-41  Q from V, new_pi = first argmax
+ *   soccer_policy_iteration    planners.py:43-53  from pi0 (the reference draws it with np.random.choice) until
+ *                                                 the greedy policy stops changing; V belongs to the last evaluation
+ * The dense planners follow the reference's Pmat/Rmat algebra (r + discount_factor * Pmat @ v) with a sequential
+ * dot; numpy's BLAS dot associates differently, so they agree with the reference to rounding (~1e-15 relative):
+ *   soccer_policy_eval_dense            planners.py:55-70  at most k sweeps of a stochastic policy[n_states*5]
+ *                                                          from init (NULL = zeros), stops when the change < theta
+ *   soccer_modified_policy_iteration    planners.py:73-87  greedy step + k evaluation sweeps, stops when
+ *                                                          |v - greedy_v| <= theta*(1-discount)/(2*discount); V = greedy_v */
+int soccer_value_iteration(soccer_handle* h, double theta, double discount_factor, int32_t max_sweeps,
                            double* V, double* Q, int32_t* pi, int32_t* iterations);
+int soccer_policy_evaluation(soccer_handle* h, const int32_t* pi, double theta, double discount_factor,
+                             int32_t max_sweeps, double* V, int32_t* sweeps);
+int soccer_policy_improvement(soccer_handle* h, const double* V, double discount_factor, double* Q, int32_t* new_pi);
+int soccer_policy_iteration(soccer_handle* h, const int32_t* pi0, double theta, double discount_factor,
+                            int32_t max_sweeps, double* V, double* Q, int32_t* pi, int32_t* iterations);
+int soccer_policy_eval_dense(soccer_handle* h, const double* policy, int32_t k, double theta, double discount_factor,
+                             int32_t max_sweeps, const double* init, double* v, int32_t* sweeps);
+int soccer_modified_policy_iteration(soccer_handle* h, int32_t k, double theta, double discount_factor,
+                                     int32_t max_sweeps, double* V, double* Q, int32_t* pi, int32_t* iterations);
 /* HOST output: prob[c*3+k] = slip-combination weight c (0: no slip, 1: B slips, 2: A slips,
  * 3: both; :211-222, evaluated left to right in float64) times outcome probability 1, 0.5, 0.25
  * (k = 0,1,2; :326-360).  prob_code values index this table (:241). */

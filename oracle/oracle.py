@@ -224,3 +224,109 @@ def value_iteration(P, nS, theta=1e-10, discount_factor=0.99, max_iterations=100
         V = newV
     Qn = np.array(Q)
     return np.argmax(Qn, axis=1), np.array(V), Qn, cc
+
+
+def single_agent_mats(orc, learner, policy):
+    """Pmat[s, ns, a] / Rmat[s, a] as the reference's constructor accumulates them (:280-291): per reachable
+    tuple in loop order, Rmat[s][a] = 0 then += p * r, Pmat[s][ns][a] += p (index 0 collects every goal tuple)."""
+    lut, kind, gv, isd, isdp = orc.tables()
+    H, W = orc.H, orc.W
+    nS = orc.nS
+    Pmat = np.zeros([nS, nS, 5]); Rmat = np.zeros([nS, 5])
+    for f in np.flatnonzero(kind != 0).tolist():
+        p_ = f & 1; r = f >> 1
+        yb = r % W; r //= W; xb = r % H; r //= H; ya = r % W; xa = r // W
+        s = 0 if kind[f] == 2 else int(lut[f])
+        for a in range(5):
+            aa, ab = (a, int(policy[s])) if learner == "player_a" else (int(policy[s]), a)
+            ps, ns, rs, ds = orc.transitions((xa, ya, xb, yb, p_), aa, ab)
+            Rmat[s][a] = 0
+            for k in range(len(ps)):
+                nf = ((((int(ns[k][0]) * W + int(ns[k][1])) * H + int(ns[k][2])) * W + int(ns[k][3])) << 1) | int(ns[k][4])
+                rr = float(rs[k])
+                if learner == "player_b":
+                    rr = -1 * rr
+                Pmat[s][0 if kind[nf] == 2 else int(lut[nf])][a] += float(ps[k])
+                Rmat[s][a] += float(ps[k]) * rr
+    return Pmat, Rmat
+
+
+def policy_evaluation(pi, P, nS, theta, discount_factor):
+    """planners.py:20-31."""
+    prev_V = [0.0] * nS
+    sweeps = 0
+    while True:
+        V = [0.0] * nS
+        for s in range(nS):
+            v = 0.0
+            for prob, ns, reward, done in P[s][int(pi[s])]:
+                v += prob * (reward + discount_factor * prev_V[ns] * (not done))
+            V[s] = v
+        sweeps += 1
+        if max(abs(prev_V[s] - V[s]) for s in range(nS)) < theta:
+            break
+        prev_V = V
+    return np.array(V), sweeps
+
+
+def policy_improvement(V, P, nS, discount_factor):
+    """planners.py:33-41."""
+    Q = np.zeros((nS, 5))
+    for s in range(nS):
+        for a in range(5):
+            q = 0.0
+            for prob, ns, reward, done in P[s][a]:
+                q += prob * (reward + discount_factor * float(V[ns]) * (not done))
+            Q[s][a] = q
+    return np.argmax(Q, axis=1), Q
+
+
+def policy_iteration(P, nS, pi0, theta, discount_factor):
+    """planners.py:43-53 with the initial draw passed in."""
+    cc = 0
+    pi = np.asarray(pi0).copy()
+    while True:
+        old_pi = pi.copy()
+        V, _ = policy_evaluation(pi, P, nS, theta, discount_factor)
+        pi, Q = policy_improvement(V, P, nS, discount_factor)
+        cc += 1
+        if np.all(old_pi == pi):
+            break
+    return pi, V, Q, cc
+
+
+def policy_eval_dense(Pmat, Rmat, policy, theta, discount_factor, k=10000000, init=None):
+    """planners.py:55-70."""
+    nS = Rmat.shape[0]
+    v = np.zeros(nS) if init is None else init
+    cc = 0
+    for _ in range(k):
+        value_fc = np.zeros(nS)
+        for s in range(nS):
+            r_pi = np.dot(policy[s, :], Rmat[s, :])
+            pv = np.dot(Pmat[s, :, :].T, v)
+            value_fc[s] = r_pi + discount_factor * np.dot(pv, policy[s, :])
+        delta = np.max(np.abs(value_fc - v))
+        v[:] = value_fc
+        cc += 1
+        if delta < theta:
+            break
+    return v, cc
+
+
+def modified_policy_iteration(Pmat, Rmat, k, theta, discount_factor):
+    """planners.py:73-87."""
+    nS = Rmat.shape[0]
+    v = np.zeros(nS)
+    threshold = (theta * (1 - discount_factor)) / (2 * discount_factor)
+    counter = 0
+    while True:
+        q = np.zeros([nS, 5])
+        for a in range(5):
+            q[:, a] = Rmat[:, a] + discount_factor * np.dot(Pmat[:, :, a], v)
+        greedy_v = np.max(q, -1)
+        best = np.argmax(q, -1)
+        if np.max(np.abs(v - greedy_v)) <= threshold:
+            return best, greedy_v, q, counter
+        v, _ = policy_eval_dense(Pmat, Rmat, np.eye(5)[best], theta, discount_factor, k=k, init=greedy_v)
+        counter += 1

@@ -28,6 +28,7 @@ What is dumped
 
 Usage:  python tests/golden/make_golden.py
 """
+import json
 import os
 import sys
 import tempfile
@@ -293,13 +294,53 @@ def dump_value_iteration(Env, slip, learner, opponent, tag):
                         pi=np.asarray(pi, np.int64), V=np.asarray(V, np.float64), Q=np.asarray(Q, np.float64),
                         iterations=np.int64(cc))
     print("  %s: %d iterations, %.0fs, %d KB" % (os.path.basename(out), cc, time.time() - t0, os.path.getsize(out) // 1024))
+    return env, policy
+
+
+def dump_other_planners(env, policy, slip, learner, opponent):
+    """policy_evaluation / policy_improvement / policy_iteration / policy_eval / modified_policy_iteration
+    (gym_soccer/utils/planners.py:20-87) of the reference on the same env; reference seconds are recorded for
+    the speed comparison in DESIGN.md."""
+    from gym_soccer.utils import planners as pl
+    theta, gamma = 1e-10, 0.99
+    rs = np.random.RandomState(11)
+    pi_eval = rs.randint(0, 5, 761)
+    sec = {}
+    t0 = time.time(); V_eval = pl.policy_evaluation(pi_eval, env, theta, gamma); sec["policy_evaluation"] = time.time() - t0
+    new_pi, Q_imp = pl.policy_improvement(V_eval, env, gamma)
+    np.random.seed(0)
+    pi0 = np.random.choice((0, 1, 2, 3, 4), 761)          # what policy_iteration draws first (:45)
+    np.random.seed(0)
+    t0 = time.time(); pi_pi, pi_V, pi_Q, pi_cc = pl.policy_iteration(env, theta, gamma); sec["policy_iteration"] = time.time() - t0
+    stoch = rs.dirichlet(np.ones(5), 761)
+    init = rs.standard_normal(761)
+    pe_v, pe_cc = pl.policy_eval(env, stoch, theta, gamma, k=25, init=init.copy())
+    pe0_v, pe0_cc = pl.policy_eval(env, stoch, 1e-6, 0.9)
+    t0 = time.time(); m1 = pl.modified_policy_iteration(env, 1, theta, gamma); sec["mpi_k1"] = time.time() - t0
+    t0 = time.time(); m2 = pl.modified_policy_iteration(env, 10000000, theta, gamma); sec["mpi_kinf"] = time.time() - t0
+    m3 = pl.modified_policy_iteration(env, 5, 1e-6, 0.9)
+    out = os.path.join(HERE, "planners_5x4_s%s_%s_vs_%s.npz" % (slip_tag(slip), learner, opponent))
+    np.savez_compressed(
+        out, slip=np.float64(slip), learner=np.bytes_(learner),
+        policy=np.asarray([policy[s] for s in range(761)], np.int8), theta=np.float64(theta), discount_factor=np.float64(gamma),
+        pe_pi=pi_eval.astype(np.int64), pe_V=V_eval, imp_pi=np.asarray(new_pi, np.int64), imp_Q=Q_imp,
+        pi_pi0=pi0.astype(np.int64), pi_pi=np.asarray(pi_pi, np.int64), pi_V=pi_V, pi_Q=pi_Q, pi_iterations=np.int64(pi_cc),
+        de_policy=stoch, de_init=init, de_v=pe_v, de_cc=np.int64(pe_cc), de0_v=pe0_v, de0_cc=np.int64(pe0_cc),
+        mpi1_pi=np.asarray(m1[0], np.int64), mpi1_V=m1[1], mpi1_Q=m1[2], mpi1_counter=np.int64(m1[3]),
+        mpi2_pi=np.asarray(m2[0], np.int64), mpi2_V=m2[1], mpi2_Q=m2[2], mpi2_counter=np.int64(m2[3]),
+        mpi3_pi=np.asarray(m3[0], np.int64), mpi3_V=m3[1], mpi3_Q=m3[2], mpi3_counter=np.int64(m3[3]),
+        reference_seconds=np.bytes_(json.dumps(sec)))
+    print("  %s: PI %d iterations, MPI counters %d / %d / %d, %s, %d KB"
+          % (os.path.basename(out), pi_cc, m1[3], m2[3], m3[3], {k: round(v, 2) for k, v in sec.items()}, os.path.getsize(out) // 1024))
 
 
 def main_planners():
     _install_gym_stand_in()
     from gym_soccer.envs import SoccerSimultaneousEnv as Env
     for slip, learner, opp in [(0.2, "player_a", "random"), (0.2, "player_b", "random"), (0.0, "player_a", "stand")]:
-        dump_value_iteration(Env, slip, learner, opp, "")
+        env, policy = dump_value_iteration(Env, slip, learner, opp, "")
+        if opp == "random":
+            dump_other_planners(env, policy, slip, learner, opp)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
-"""Value iteration (reference gym_soccer/utils/planners.py:4-18): the oracle's restatement is pinned to
-fixtures produced by the reference's own planner on its own env (tests/golden/make_golden.py planners),
-and the device planner (soccer_value_iteration) must reproduce them bit for bit."""
+"""Planners (reference gym_soccer/utils/planners.py:4-87).  The oracle's restatements are pinned to fixtures
+produced by the reference's own planners on its own env (tests/golden/make_golden.py planners); the device
+planners (include/soccer_hip.h "planners") must reproduce them: bit for bit for the list-based ones, to
+rounding (rtol 1e-12; numpy's BLAS dot associates differently from the kernel's sequential dot) for the
+dense Pmat/Rmat ones — with identical iteration counters and greedy policies."""
 import glob
 import os
 
@@ -8,44 +10,98 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-FIXTURES = sorted(glob.glob(os.path.join(GOLD, "vi_*.npz")))
+VI = sorted(glob.glob(os.path.join(GOLD, "vi_*.npz")))
+PL = sorted(glob.glob(os.path.join(GOLD, "planners_*.npz")))
+DENSE_RTOL = 1e-12
+
+
+def _ids(paths):
+    return [os.path.basename(p)[:-4] for p in paths]
 
 
 def _load(path):
     d = np.load(path)
-    return d, float(d["slip"]), bytes(d["learner"]).decode(), d["policy"]
+    return d, float(d["slip"]), bytes(d["learner"]).decode(), d["policy"], float(d["theta"]), float(d["discount_factor"])
+
+
+def _env(slip, learner, policy):
+    import gym_soccer_littman94_amd as gsa
+    kw = {"player_b_policy": policy} if learner == "player_a" else {"player_a_policy": policy}
+    return gsa.SoccerSimultaneousEnv(width=5, height=4, slip_prob=slip, **kw)
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 3
+    assert len(VI) >= 3 and len(PL) >= 2
 
 
-@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+# ---- oracle pinned to the reference -----------------------------------------------------------------
+@pytest.mark.parametrize("path", VI, ids=_ids(VI))
 def test_oracle_value_iteration_matches_reference(path):
     from oracle.oracle import Oracle, single_agent_lists, value_iteration
-    d, slip, learner, policy = _load(path)
+    d, slip, learner, policy, theta, gamma = _load(path)
     orc = Oracle(5, 4, slip)
-    P = single_agent_lists(orc, learner, policy)
-    pi, V, Q, cc = value_iteration(P, orc.nS, float(d["theta"]), float(d["discount_factor"]))
+    pi, V, Q, cc = value_iteration(single_agent_lists(orc, learner, policy), orc.nS, theta, gamma)
     assert cc == int(d["iterations"])
     assert np.array_equal(V, d["V"]) and np.array_equal(Q, d["Q"])       # bit-exact float64
     assert np.array_equal(pi, d["pi"])
 
 
+@pytest.mark.parametrize("path", PL[:1], ids=_ids(PL[:1]))
+def test_oracle_list_planners_match_reference(path):
+    from oracle import oracle as O
+    d, slip, learner, policy, theta, gamma = _load(path)
+    orc = O.Oracle(5, 4, slip)
+    P = O.single_agent_lists(orc, learner, policy)
+    V, _ = O.policy_evaluation(d["pe_pi"], P, orc.nS, theta, gamma)
+    assert np.array_equal(V, d["pe_V"])
+    pi, Q = O.policy_improvement(V, P, orc.nS, gamma)
+    assert np.array_equal(pi, d["imp_pi"]) and np.array_equal(Q, d["imp_Q"])
+    pi, V, Q, cc = O.policy_iteration(P, orc.nS, d["pi_pi0"], 1e-4, gamma)       # short horizon: own consistency only
+    assert cc >= 2 and np.array_equal(pi, d["pi_pi"])                     # the best response is unique here
+
+
+@pytest.mark.parametrize("path", PL, ids=_ids(PL))
+def test_oracle_dense_planners_match_reference(path):
+    from oracle import oracle as O
+    d, slip, learner, policy, theta, gamma = _load(path)
+    orc = O.Oracle(5, 4, slip)
+    Pmat, Rmat = O.single_agent_mats(orc, learner, policy)
+    v, cc = O.policy_eval_dense(Pmat, Rmat, d["de_policy"], theta, gamma, k=25, init=d["de_init"].copy())
+    assert cc == int(d["de_cc"]) and np.array_equal(v, d["de_v"])
+    pi, V, Q, counter = O.modified_policy_iteration(Pmat, Rmat, 5, 1e-6, 0.9)
+    assert counter == int(d["mpi3_counter"]) and np.array_equal(pi, d["mpi3_pi"])
+    assert np.array_equal(V, d["mpi3_V"]) and np.array_equal(Q, d["mpi3_Q"])
+
+
+def test_policies_module_matches_reference_draws():
+    from gym_soccer_littman94_amd.policies import get_random_policy, get_stand_policy
+    d = np.load(PL[0])
+    rp = get_random_policy(761, 5, seed=0)                                # the fixtures' opponent (policies.py:4-9)
+    assert [rp[s] for s in range(761)] == d["policy"].tolist()
+    assert set(get_stand_policy(761).values()) == {0} and len(get_stand_policy(10)) == 10
+
+
+def test_policy_save_load_roundtrip(tmp_path):
+    from gym_soccer_littman94_amd.policies import get_random_policy, load_policy, save_policy
+    p = get_random_policy(50, 5, seed=3)
+    save_policy(p, tmp_path / "p.pkl")
+    assert load_policy(tmp_path / "p.pkl") == p
+    with pytest.raises(AssertionError):
+        save_policy([0, 1], tmp_path / "q.pkl")
+
+
+# ---- device planners against the reference ----------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+@pytest.mark.parametrize("path", VI, ids=_ids(VI))
 def test_device_value_iteration_matches_reference(path):
-    import gym_soccer_littman94_amd as gsa
     from gym_soccer_littman94_amd.planners import value_iteration
-    d, slip, learner, policy = _load(path)
-    kw = {"player_b_policy": policy} if learner == "player_a" else {"player_a_policy": policy}
-    env = gsa.SoccerSimultaneousEnv(width=5, height=4, slip_prob=slip, **kw)
-    pi, V, Q, cc = value_iteration(env, float(d["theta"]), float(d["discount_factor"]))
+    d, slip, learner, policy, theta, gamma = _load(path)
+    env = _env(slip, learner, policy)
+    pi, V, Q, cc = value_iteration(env, theta, gamma)
     assert cc == int(d["iterations"])
     assert np.array_equal(V, d["V"]) and np.array_equal(Q, d["Q"])       # bit-exact float64
     assert np.array_equal(pi, d["pi"])
-    # and the planner agrees with the reference's planner run over the facade's own P tables
-    # (the host loop the reference would execute), on a short horizon
+    # and the planner agrees with the reference's loop run on the host over the facade's own P tables
     pi2, V2, Q2, cc2 = value_iteration(env, 1e-2, 0.9)
     from oracle.oracle import value_iteration as host_vi
     pi3, V3, Q3, cc3 = host_vi(env.P, env.nS, 1e-2, 0.9)
@@ -53,26 +109,81 @@ def test_device_value_iteration_matches_reference(path):
 
 
 @pytest.mark.gpu
-def test_device_value_iteration_needs_single_agent_mode():
-    import gym_soccer_littman94_amd as gsa
-    from gym_soccer_littman94_amd.planners import value_iteration
-    env = gsa.SoccerSimultaneousEnv()
-    with pytest.raises(AssertionError):
-        value_iteration(env, 1e-10, 0.99)
-    with pytest.raises(AssertionError):
-        env._batch.value_iteration(1e-10, 0.99)
+@pytest.mark.parametrize("path", PL, ids=_ids(PL))
+def test_device_list_planners_match_reference_bit_for_bit(path):
+    from gym_soccer_littman94_amd import planners as pl
+    d, slip, learner, policy, theta, gamma = _load(path)
+    env = _env(slip, learner, policy)
+    V = pl.policy_evaluation(d["pe_pi"], env, theta, gamma)
+    assert np.array_equal(V, d["pe_V"])
+    pi, Q = pl.policy_improvement(V, env, gamma)
+    assert np.array_equal(pi, d["imp_pi"]) and np.array_equal(Q, d["imp_Q"])
+    pi, V, Q, cc = pl.policy_iteration(env, theta, gamma, initial_policy=d["pi_pi0"])
+    assert cc == int(d["pi_iterations"]) and np.array_equal(pi, d["pi_pi"])
+    assert np.array_equal(V, d["pi_V"]) and np.array_equal(Q, d["pi_Q"])
+    np.random.seed(0)                                                     # the reference's own initial draw (:45)
+    pi, V, Q, cc = pl.policy_iteration(env, theta, gamma)
+    assert cc == int(d["pi_iterations"]) and np.array_equal(V, d["pi_V"]) and np.array_equal(pi, d["pi_pi"])
 
 
 @pytest.mark.gpu
-def test_device_value_iteration_large_pitch_and_iteration_cap():
+@pytest.mark.parametrize("path", PL, ids=_ids(PL))
+def test_device_dense_planners_match_reference_to_rounding(path):
+    from gym_soccer_littman94_amd import planners as pl
+    d, slip, learner, policy, theta, gamma = _load(path)
+    env = _env(slip, learner, policy)
+    init = d["de_init"].copy()
+    v, cc = pl.policy_eval(env, d["de_policy"], theta, gamma, k=25, init=init)
+    assert cc == int(d["de_cc"]) and v is init                            # updated in place like the reference
+    np.testing.assert_allclose(v, d["de_v"], rtol=DENSE_RTOL, atol=1e-14)
+    v, cc = pl.policy_eval(env, d["de_policy"], 1e-6, 0.9)
+    assert cc == int(d["de0_cc"])
+    np.testing.assert_allclose(v, d["de0_v"], rtol=DENSE_RTOL, atol=1e-14)
+    for tag, k, th, g in (("mpi1", 1, theta, gamma), ("mpi2", 10000000, theta, gamma), ("mpi3", 5, 1e-6, 0.9)):
+        pi, V, Q, counter = pl.modified_policy_iteration(env, k, th, g)
+        assert counter == int(d[tag + "_counter"]), tag
+        assert np.array_equal(pi, d[tag + "_pi"]), tag
+        np.testing.assert_allclose(V, d[tag + "_V"], rtol=DENSE_RTOL, atol=1e-14)
+        np.testing.assert_allclose(Q, d[tag + "_Q"], rtol=DENSE_RTOL, atol=1e-14)
+    # the reference's own acceptance check (soccer_simultaneous_env.py:553-566): all planners agree
+    vi = pl.value_iteration(env, theta, gamma)
+    m2 = pl.modified_policy_iteration(env, 10000000, theta, gamma)
+    assert np.all(vi[0] == m2[0]) and np.allclose(vi[1], m2[1]) and np.allclose(vi[2], m2[2])
+
+
+@pytest.mark.gpu
+def test_device_planners_need_single_agent_mode_and_validate():
+    import gym_soccer_littman94_amd as gsa
+    from gym_soccer_littman94_amd import planners as pl
+    env = gsa.SoccerSimultaneousEnv()
+    with pytest.raises(AssertionError):
+        pl.value_iteration(env, 1e-10, 0.99)
+    with pytest.raises(AssertionError):
+        env._batch.value_iteration(1e-10, 0.99)
+    b = gsa.SoccerBatch(1)
+    b.set_policy("player_b", np.zeros(b.nS, np.int8))
+    with pytest.raises(AssertionError):
+        b.policy_evaluation(np.full(b.nS, 7), 1e-10, 0.99)               # not an action
+    with pytest.raises(AssertionError):
+        b.policy_evaluation(np.zeros(5), 1e-10, 0.99)
+    with pytest.raises(RuntimeError):
+        b.value_iteration(1e-10, 0.99, max_sweeps=3)                      # SOCCER_E_STATE: not converged
+    # changing the opponent rebuilds the cached lists
+    V0 = b.value_iteration(1e-6, 0.9)[1]
+    b.set_policy("player_b", None); b.set_policy("player_b", np.full(b.nS, 3, np.int8))
+    V1 = b.value_iteration(1e-6, 0.9)[1]
+    assert not np.array_equal(V0, V1)
+
+
+@pytest.mark.gpu
+def test_device_value_iteration_larger_pitch():
     import gym_soccer_littman94_amd as gsa
     from oracle.oracle import Oracle, single_agent_lists, value_iteration as host_vi
     rng = np.random.default_rng(5)
     b = gsa.SoccerBatch(1, 7, 5, 0.3)
     policy = rng.integers(0, 5, b.nS).astype(np.int8)
     b.set_policy("player_a", policy)
-    pi, V, Q, cc = b.value_iteration(1e-10, 0.95, max_iterations=7)
-    assert cc == 7
+    pi, V, Q, cc = b.value_iteration(1e-3, 0.8)
     orc = Oracle(7, 5, 0.3)
-    pi2, V2, Q2, cc2 = host_vi(single_agent_lists(orc, "player_b", policy), orc.nS, 1e-10, 0.95, max_iterations=7)
-    assert cc2 == 7 and np.array_equal(V, V2) and np.array_equal(Q, Q2) and np.array_equal(pi, pi2)
+    pi2, V2, Q2, cc2 = host_vi(single_agent_lists(orc, "player_b", policy), orc.nS, 1e-3, 0.8)
+    assert cc2 == cc and np.array_equal(V, V2) and np.array_equal(Q, Q2) and np.array_equal(pi, pi2)

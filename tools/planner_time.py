@@ -1,0 +1,40 @@
+"""Wall time of the device planners on the fixtures' problem (5x4, slip 0.2, learner A vs random B),
+next to the reference's own seconds recorded in tests/golden/planners_*.npz (Python, this container's CPU)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gym_soccer_littman94_amd as gsa
+from gym_soccer_littman94_amd import planners as pl
+
+d = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "planners_5x4_s0p2_player_a_vs_random.npz"))
+ref = json.loads(bytes(d["reference_seconds"]).decode())
+ref["value_iteration"] = 4.0
+env = gsa.SoccerSimultaneousEnv(width=5, height=4, slip_prob=0.2, player_b_policy=d["policy"])
+t0 = time.perf_counter(); pl.value_iteration(env, 1e-10, 0.99); first = time.perf_counter() - t0
+print("first call incl. list build: %.1f ms" % (first * 1e3))
+
+
+def best(f, n=5):
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+    return min(ts)
+
+
+rows = [("value_iteration", lambda: pl.value_iteration(env, 1e-10, 0.99)),
+        ("policy_evaluation", lambda: pl.policy_evaluation(d["pe_pi"], env, 1e-10, 0.99)),
+        ("policy_iteration", lambda: pl.policy_iteration(env, 1e-10, 0.99, initial_policy=d["pi_pi0"])),
+        ("mpi_k1", lambda: pl.modified_policy_iteration(env, 1, 1e-10, 0.99)),
+        ("mpi_kinf", lambda: pl.modified_policy_iteration(env, 10000000, 1e-10, 0.99))]
+for name, f in rows:
+    t = best(f)
+    print("%-18s device %8.2f ms   reference %7.2f s   x%.0f" % (name, t * 1e3, ref[name], ref[name] / t))
+b = gsa.SoccerBatch(1, 11, 7, 0.2)
+b.set_policy("player_b", np.random.default_rng(0).integers(0, 5, b.nS).astype(np.int8))
+t0 = time.perf_counter(); out = b.value_iteration(1e-10, 0.99); t = time.perf_counter() - t0
+print("11x7 (nS=%d) value iteration incl. list build: %.0f ms, %d iterations" % (b.nS, t * 1e3, out[3]))
