@@ -749,17 +749,20 @@ static int build_plan(soccer_handle* h) {
     // P[s][a]: goal tuples all write index 0 and overwrite each other (identical lists), live tuples own theirs
     std::vector<long> tuple_of(nS, -1);
     for (size_t f = 0; f < T; ++f) if (R.kind[f] != 0) tuple_of[obs_of(f)] = (long)f;
-    std::vector<int32_t> off((size_t)nS * 5 + 1, 0), c_next; std::vector<double> c_prob, c_rew; std::vector<uint8_t> c_done;
+    const PlanEntry pad_entry{0.0, (int32_t)0x80000000, 0.0f};
+    auto pad = [&](std::vector<PlanEntry>& v) { while (v.size() % kPlanPad) v.push_back(pad_entry); };
+    std::vector<int32_t> off((size_t)nS * 5 + 1, 0); std::vector<PlanEntry> lists;
     for (int s = 0; s < nS; ++s) for (int a = 0; a < 5; ++a) {
         const long f = tuple_of[s];
         if (f < 0) return fail(h, SOCCER_E_INVALID, "internal error: observation index %d has no tuple", s);
         const size_t key = (size_t)f * 25 + (fixed_a ? policy[s] : a) * 5 + (fixed_b ? policy[s] : a);
         for (int k = 0; k < count[key]; ++k) {
             const size_t e = key * kMaxOutcomes + k;
-            c_prob.push_back(prob[e]); c_next.push_back(obs_of((size_t)nxt[e]));
-            c_rew.push_back(flip ? -1.0 * (double)rew[e] : (double)rew[e]); c_done.push_back(done[e]);
+            const double rr = flip ? -1.0 * (double)rew[e] : (double)rew[e];
+            lists.push_back(PlanEntry{prob[e], obs_of((size_t)nxt[e]) | (done[e] ? (int32_t)0x80000000 : 0), (float)rr});
         }
-        off[(size_t)s * 5 + a + 1] = (int32_t)c_prob.size();
+        pad(lists);
+        off[(size_t)s * 5 + a + 1] = (int32_t)lists.size();
     }
     // Pmat[s][ns][a] += p and Rmat[s][a] (= 0, then += p * r) in the constructor's tuple order (:280-291):
     // index 0 accumulates one unit of probability per goal tuple, its Rmat is the last goal tuple's (0)
@@ -782,22 +785,20 @@ static int build_plan(soccer_handle* h) {
             Rm[(size_t)s * 5 + a] = acc;
         }
     }
-    std::vector<int32_t> m_off((size_t)nS * 5 + 1, 0), m_next; std::vector<double> m_prob;
+    std::vector<int32_t> m_off((size_t)nS * 5 + 1, 0); std::vector<PlanEntry> m_lists;
+    const PlanEntry m_pad{0.0, 0, 0.0f};
     for (size_t q = 0; q < (size_t)nS * 5; ++q) {
-        for (int ns = 0; ns < nS; ++ns) if (row[q][ns] != 0.0) { m_next.push_back(ns); m_prob.push_back(row[q][ns]); }
-        m_off[q + 1] = (int32_t)m_next.size();
+        for (int ns = 0; ns < nS; ++ns) if (row[q][ns] != 0.0) m_lists.push_back(PlanEntry{row[q][ns], ns, 0.0f});
+        while (m_lists.size() % kPlanPad) m_lists.push_back(m_pad);
+        m_off[q + 1] = (int32_t)m_lists.size();
         std::vector<double>().swap(row[q]);
     }
     PlanIO& io = h->plan;
     io = PlanIO{};
     int rc = plan_upload(h, off, &io.offset);
-    if (!rc) rc = plan_upload(h, c_prob, &io.prob);
-    if (!rc) rc = plan_upload(h, c_next, &io.next);
-    if (!rc) rc = plan_upload(h, c_rew, &io.reward);
-    if (!rc) rc = plan_upload(h, c_done, &io.done);
+    if (!rc) rc = plan_upload(h, lists, &io.list);
     if (!rc) rc = plan_upload(h, m_off, &io.m_offset);
-    if (!rc) rc = plan_upload(h, m_prob, &io.m_prob);
-    if (!rc) rc = plan_upload(h, m_next, &io.m_next);
+    if (!rc) rc = plan_upload(h, m_lists, &io.m_list);
     if (!rc) rc = plan_upload(h, Rm, &io.m_R);
     const std::vector<double> zV(nS, 0.0), zQ((size_t)nS * 5, 0.0); const std::vector<int32_t> zpi(nS, 0), zc(16, 0);
     const double* cV = nullptr; const double* cN = nullptr; const double* cQ = nullptr; const int32_t* cpi = nullptr; const int32_t* cc = nullptr;

@@ -961,16 +961,19 @@ __global__ __launch_bounds__(kBlock) void enumerate_kernel(const KernelParams P,
 // =================================================================================================
 enum PlanMode : int32_t { kPlanVI = 0, kPlanEval = 1, kPlanImprove = 2, kPlanPI = 3, kPlanMPI = 4, kPlanEvalDense = 5 };
 
+// one list entry, 16 bytes = one dwordx4 load.  Lists are padded to a multiple of kPlanPad entries with
+// (prob 0, next 0, done) entries, which add an exact +-0 to the running sum, so the loops below can fetch
+// kPlanPad entries per wait without changing a bit of the result.
+struct __attribute__((aligned(16))) PlanEntry { double prob; int32_t next_done; float reward; };   // next | done << 31
+constexpr int kPlanPad = 4;
+
 struct PlanIO {
-    // P[s][a] lists in the reference's order (:167-293), CSR by (state, learner action)
-    const int32_t* offset;      // [nS*5 + 1]
-    const double* prob;
-    const int32_t* next;        // observation index of the next state
-    const double* reward;       // learner's reward (+-1, +-0)
-    const uint8_t* done;
+    // P[s][a] lists in the reference's order (:167-293), CSR by (state, learner action): offset[nS*5 + 1];
+    // reward is the learner's (+-1, +-0)
+    const int32_t* offset; const PlanEntry* list;
     // rows of Pmat / Rmat (:280-291): per (state, action) the next states in ascending index with their
     // accumulated probability (the dense dot's order), and the expected reward
-    const int32_t* m_offset; const double* m_prob; const int32_t* m_next; const double* m_R;
+    const int32_t* m_offset; const PlanEntry* m_list; const double* m_R;
     double* V; double* newV; double* Q; int32_t* pi;
     int32_t* counters;          // [0] outer iterations, [1] sweeps, [2] 1 = stopped by max_sweeps
     int32_t nS, mode, max_sweeps, k;
@@ -980,18 +983,37 @@ struct PlanIO {
 // Q += prob * (reward + discount_factor * V[next_state] * (not done)), summed in list order (planners.py:12,28,39)
 __device__ __forceinline__ double list_backup(const PlanIO& IO, const double* V, int s, int a) {
     double q = 0.0;
-    for (int e = IO.offset[s * 5 + a]; e < IO.offset[s * 5 + a + 1]; ++e) {
-        const double cont = (IO.gamma * V[IO.next[e]]) * (IO.done[e] ? 0.0 : 1.0);
-        q = q + IO.prob[e] * (IO.reward[e] + cont);
+    const int end = IO.offset[s * 5 + a + 1];
+    for (int e = IO.offset[s * 5 + a]; e < end; e += kPlanPad) {
+        PlanEntry x[kPlanPad];
+#pragma unroll
+        for (int j = 0; j < kPlanPad; ++j) x[j] = IO.list[e + j];
+#pragma unroll
+        for (int j = 0; j < kPlanPad; ++j) {
+            const double cont = (IO.gamma * V[x[j].next_done & 0x7fffffff]) * (x[j].next_done < 0 ? 0.0 : 1.0);
+            q = q + x[j].prob * ((double)x[j].reward + cont);
+        }
     }
     return q;
 }
 
+// dot(Pmat[s, :, a], v) with a sequential sum over the non-zero entries in ascending next-state index
+__device__ __forceinline__ double dense_dot(const PlanIO& IO, const double* V, int s, int a) {
+    double acc = 0.0;
+    const int end = IO.m_offset[s * 5 + a + 1];
+    for (int e = IO.m_offset[s * 5 + a]; e < end; e += kPlanPad) {
+        PlanEntry x[kPlanPad];
+#pragma unroll
+        for (int j = 0; j < kPlanPad; ++j) x[j] = IO.m_list[e + j];
+#pragma unroll
+        for (int j = 0; j < kPlanPad; ++j) acc = acc + x[j].prob * V[x[j].next_done];
+    }
+    return acc;
+}
+
 // Rmat[s, a] + discount_factor * dot(Pmat[s, :, a], v)   (planners.py:62-65, :80)
 __device__ __forceinline__ double dense_backup(const PlanIO& IO, const double* V, int s, int a) {
-    double acc = 0.0;
-    for (int e = IO.m_offset[s * 5 + a]; e < IO.m_offset[s * 5 + a + 1]; ++e) acc = acc + IO.m_prob[e] * V[IO.m_next[e]];
-    return IO.m_R[s * 5 + a] + IO.gamma * acc;
+    return IO.m_R[s * 5 + a] + IO.gamma * dense_dot(IO, V, s, a);
 }
 
 // maximum of a non-negative double over the workgroup (such doubles order like their bit patterns)
@@ -1097,8 +1119,7 @@ __global__ __launch_bounds__(1024) void planner_kernel(const PlanIO IO) {
                 double r_pi = 0.0, p_pi = 0.0;
                 for (int a = 0; a < 5; ++a) {
                     const double w = IO.Q[s * 5 + a];
-                    double acc = 0.0;
-                    for (int e = IO.m_offset[s * 5 + a]; e < IO.m_offset[s * 5 + a + 1]; ++e) acc = acc + IO.m_prob[e] * V[IO.m_next[e]];
+                    const double acc = dense_dot(IO, V, s, a);
                     r_pi = r_pi + w * IO.m_R[s * 5 + a];
                     p_pi = p_pi + acc * w;
                 }
