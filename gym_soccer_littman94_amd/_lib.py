@@ -42,6 +42,15 @@ class RolloutArgs(C.Structure):
                 ("mix_a", C.c_void_p), ("mix_b", C.c_void_p)]
 
 
+class ScalarIO(C.Structure):
+    """soccer_scalar_io"""
+    _fields_ = [("row_a", C.c_int8), ("col_a", C.c_int8), ("row_b", C.c_int8), ("col_b", C.c_int8),
+                ("poss", C.c_uint8), ("needs_reset", C.c_uint8), ("t", C.c_uint8),
+                ("act_a", C.c_int8), ("act_b", C.c_int8), ("reward", C.c_int8),
+                ("terminated", C.c_uint8), ("truncated", C.c_uint8), ("prob_code", C.c_uint8), ("pad_", C.c_uint8),
+                ("obs", C.c_uint16), ("u_step", C.c_double), ("u_reset", C.c_double)]
+
+
 class StagingView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("act_a", "act_b", "mask", "u_step", "u_reset", "obs", "final_obs",
                                          "reward", "terminated", "truncated", "prob_code")]
@@ -74,6 +83,8 @@ PROTOTYPES = {
     "soccer_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
     "soccer_get_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "soccer_enumerate_transitions": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    "soccer_step_scalar": (C.c_int, [C.c_void_p, C.POINTER(ScalarIO)]),
+    "soccer_reset_scalar": (C.c_int, [C.c_void_p, C.POINTER(ScalarIO)]),
     "soccer_value_iteration": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.POINTER(C.c_int32)]),
     "soccer_policy_evaluation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p,

@@ -173,6 +173,29 @@ class SoccerBatch:
                                                           nxt.ctypes.data, rew.ctypes.data, done.ctypes.data))
         return count, prob, nxt, rew, done
 
+    # -- one environment, lowest latency (n_lanes == 1) ------------------------------------------------
+    def step_scalar(self, state, act_a, act_b, u_step, t=0, u_reset=0.0):
+        """soccer_step_scalar: (row_a, col_a, row_b, col_b, poss), actions, uniform -> dict with the next
+        tuple, t, needs_reset, obs, reward, terminated, truncated, prob_code."""
+        io = _lib.ScalarIO()
+        io.row_a, io.col_a, io.row_b, io.col_b, io.poss = (int(x) for x in state)
+        io.t = int(t); io.act_a = int(act_a or 0); io.act_b = int(act_b or 0)
+        io.u_step = float(u_step); io.u_reset = float(u_reset)
+        self._check(self.lib.soccer_step_scalar(self.h, C.byref(io)))
+        return self._scalar_out(io)
+
+    def reset_scalar(self, u_reset):
+        io = _lib.ScalarIO()
+        io.u_reset = float(u_reset)
+        self._check(self.lib.soccer_reset_scalar(self.h, C.byref(io)))
+        return self._scalar_out(io)
+
+    @staticmethod
+    def _scalar_out(io):
+        return {"state": (io.row_a, io.col_a, io.row_b, io.col_b, io.poss), "t": io.t, "needs_reset": io.needs_reset,
+                "obs": io.obs, "reward": io.reward, "terminated": io.terminated, "truncated": io.truncated,
+                "prob_code": io.prob_code}
+
     # -- planners on the device (single-agent mode; reference utils/planners.py) ------------------
     def _plan_out(self):
         return (np.zeros(self.nS, np.float64), np.zeros((self.nS, 5), np.float64), np.zeros(self.nS, np.int32), C.c_int32())

@@ -6,6 +6,7 @@
 // is a kernel launch, and a missing/failed device is an error, not a fallback.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -55,6 +56,7 @@ struct soccer_handle {
     uint64_t capture_ticks = 0;
     int capture_calls = 0;
     int capture_start_slot = 0;
+    uint4* rec_host = nullptr; uint4* rec_dev = nullptr; uint32_t rec_seq = 0;   // soccer_step_scalar's mapped result record
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
     bool plan_ready = false;
@@ -101,6 +103,7 @@ static void free_handle(soccer_handle* h) {
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
+    if (h->rec_host) (void)hipHostFree(h->rec_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -643,6 +646,65 @@ extern "C" int batched_reset_staged(soccer_handle* h, uint32_t use) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SOCCER_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// one environment, one call: inputs by value, result polled from a mapped record (see scalar_kernel)
+static int scalar_call(soccer_handle* h, const char* what, uint32_t op, soccer_scalar_io* io) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (!io) return fail(h, SOCCER_E_INVALID, "%s: io is NULL", what);
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "%s during graph capture", what);
+    if (h->P.n != 1) return fail(h, SOCCER_E_INVALID, "%s needs a handle with n_lanes == 1", what);
+    const Rules& R = h->rules;
+    ScalarIO k{};
+    k.op = op; k.u_step = io->u_step; k.u_reset = io->u_reset;
+    if (op == 0u) {
+        if (io->needs_reset) return fail(h, SOCCER_E_INVALID, "Please reset the environment before taking a step");   // :376
+        const int ra = io->row_a, ca = io->col_a, rb = io->row_b, cb = io->col_b;
+        if (ra < 0 || ra >= R.H || rb < 0 || rb >= R.H || ca < 0 || ca >= R.W || cb < 0 || cb >= R.W || io->poss > 1)
+            return fail(h, SOCCER_E_INVALID, "%s: tuple (%d, %d, %d, %d, %d) is outside the pitch", what, ra, ca, rb, cb, (int)io->poss);
+        if (R.kind[((((size_t)ra * R.W + ca) * R.H + rb) * R.W + cb) * 2 + io->poss] == 0)
+            return fail(h, SOCCER_E_INVALID, "%s: tuple (%d, %d, %d, %d, %d) is unreachable", what, ra, ca, rb, cb, (int)io->poss);
+        if ((int)io->t > h->cfg.max_steps) return fail(h, SOCCER_E_INVALID, "%s: t = %d exceeds max_steps", what, (int)io->t);
+        if ((!h->P.policy_a && (io->act_a < 0 || io->act_a > 4)) || (!h->P.policy_b && (io->act_b < 0 || io->act_b > 4)))
+            return fail(h, SOCCER_E_INVALID, "%s: actions must be in 0..4", what);
+        k.pos = (uint32_t)ra | ((uint32_t)ca << 8) | ((uint32_t)rb << 16) | ((uint32_t)cb << 24);
+        k.misc = (uint32_t)io->poss | ((uint32_t)io->t << 8) | ((uint32_t)(uint8_t)io->act_a << 16) | ((uint32_t)(uint8_t)io->act_b << 24);
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->rec_host) {
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->rec_host), 64, hipHostMallocMapped));
+        std::memset(h->rec_host, 0, 64);
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rec_dev), h->rec_host, 0));
+    }
+    k.seq = ++h->rec_seq ? h->rec_seq : ++h->rec_seq;                    // never 0
+    k.record = h->rec_dev;
+    KernelParams P = h->P;
+    bind_tick(h, P, 1);
+    if (h->slip) hipLaunchKernelGGL(scalar_kernel<true>, dim3(1), dim3(64), 0, h->stream, P, k);
+    else hipLaunchKernelGGL(scalar_kernel<false>, dim3(1), dim3(64), 0, h->stream, P, k);
+    HIP_TRY(h, hipGetLastError());
+    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->rec_host);
+    for (uint32_t spins = 0; *flag != k.seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfffffu) == 0xfffffu) {                            // every ~10 ms: has the stream died?
+            const hipError_t e = hipStreamQuery(h->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "%s: %s", what, hipGetErrorString(e));
+            if (e == hipSuccess && *flag != k.seq) return fail(h, SOCCER_E_HIP, "%s: the kernel finished without publishing its record", what);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const volatile uint32_t* r = flag;
+    const uint32_t res = r[1], npos = r[2], nm = r[3];
+    io->obs = (uint16_t)(res & 0xffffu); io->reward = (int8_t)((res >> 16) & 0xffu);
+    io->terminated = (res >> 24) & 1u; io->truncated = (res >> 25) & 1u; io->prob_code = (uint8_t)(res >> 26);
+    io->row_a = (int8_t)(npos & 0xffu); io->col_a = (int8_t)((npos >> 8) & 0xffu);
+    io->row_b = (int8_t)((npos >> 16) & 0xffu); io->col_b = (int8_t)(npos >> 24);
+    io->poss = nm & 1u; io->needs_reset = (nm >> 1) & 1u; io->t = (uint8_t)(nm >> 8);
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_step_scalar(soccer_handle* h, soccer_scalar_io* io) { return scalar_call(h, "soccer_step_scalar", 0u, io); }
+extern "C" int soccer_reset_scalar(soccer_handle* h, soccer_scalar_io* io) { return scalar_call(h, "soccer_reset_scalar", 1u, io); }
 
 // host arrays in, host arrays out: copies through the staging block around the *_staged calls
 extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {

@@ -786,6 +786,59 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KernelParams P, con
 }
 
 // =================================================================================================
+// one environment, one step or reset, lowest latency (the single-env facade's path; reference :375-424)
+// =================================================================================================
+// Inputs arrive BY VALUE as kernel arguments and the results leave as ONE 16-byte store to a host-mapped
+// record the host polls: the GPU reads no host memory and the host never enters a stream synchronisation
+// (tools/latency_lab.hip: 7.9 us for launch + kernel-written flag + poll against 12.6 us for launch +
+// hipStreamSynchronize).  The lane's resident state streams are updated too.
+struct ScalarIO {
+    uint32_t pos;       // row_a | col_a << 8 | row_b << 16 | col_b << 24
+    uint32_t misc;      // poss | t << 8 | act_a << 16 | act_b << 24
+    uint32_t op;        // 0 step, 1 reset
+    uint32_t seq;       // written to record.x last
+    double u_step, u_reset;
+    uint4* record;      // host-mapped: { seq, obs | (reward & 0xff) << 16 | term << 24 | trunc << 25 | code << 26,
+                        //                next pos (as `pos`), poss | needs_reset << 1 | t << 8 }
+};
+
+template <bool SLIP>
+__global__ __launch_bounds__(64) void scalar_kernel(const KernelParams P, const ScalarIO IO) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long tick = *P.tick_in;
+    *P.tick_out = tick + 1ull;
+    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
+    Lane L; StepResult R;
+    R.obs = 0u; R.final_obs = 0u; R.reward = 0; R.term = 0u; R.trunc = 0u; R.code = 0u; R.finished = 0u;
+    if (IO.op == 1u) {
+        uint32_t ob = 0u;
+        lane_reset(T, P, L, (uint32_t)(sane_uniform(IO.u_reset) * 4.0), ob);
+        R.obs = ob;
+    } else {
+        L.A = make_pos(IO.pos & 0xffu, (IO.pos >> 8) & 0xffu, P.W);
+        L.B = make_pos((IO.pos >> 16) & 0xffu, IO.pos >> 24, P.W);
+        L.p = IO.misc & 1u; L.need = 0u; L.t = (IO.misc >> 8) & 0xffu;
+        uint32_t a_now = (IO.misc >> 16) & 0xffu, b_now = IO.misc >> 24;
+        if (P.policy_a || P.policy_b) {                             // the fixed side acts on the current observation
+            const uint32_t s_now = obs_of(T, P, L.A, L.B, L.p);
+            if (P.policy_a) a_now = (uint32_t)(uint8_t)P.policy_a[s_now];
+            if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
+        }
+        const double u = sane_uniform(IO.u_step);
+        const Draw d{u, (uint32_t)(u * 4.0), (uint32_t)(sane_uniform(IO.u_reset) * 4.0)};
+        (void)lane_step<SLIP>(T, P, L, a_now, b_now, d, R);
+    }
+    uint8_t* sw = P.state;
+    sw[0] = (uint8_t)(L.A >> 24); sw[P.state_stride] = (uint8_t)(L.A >> 16);
+    sw[2 * P.state_stride] = (uint8_t)(L.B >> 24); sw[3 * P.state_stride] = (uint8_t)(L.B >> 16);
+    sw[4 * P.state_stride] = (uint8_t)(L.p | (L.need << 1)); sw[5 * P.state_stride] = (uint8_t)L.t;
+    __threadfence_system();
+    const uint32_t res = R.obs | (((uint32_t)R.reward & 0xffu) << 16) | (R.term << 24) | (R.trunc << 25) | (R.code << 26);
+    const uint32_t npos = (L.A >> 24) | (((L.A >> 16) & 0xffu) << 8) | ((L.B >> 24) << 16) | (((L.B >> 16) & 0xffu) << 24);
+    *IO.record = make_uint4(IO.seq, res, npos, L.p | (L.need << 1) | (L.t << 8));
+}
+
+// =================================================================================================
 // batched_rollout: T fused steps, state in registers, actions streamed in, trajectories streamed out
 // =================================================================================================
 // DYN = false: both action streams come from memory (the trajectory collector); the code for in-kernel

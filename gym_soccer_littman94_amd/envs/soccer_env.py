@@ -5,15 +5,18 @@ Drop-in for `gym_soccer.envs.SoccerSimultaneousEnv`
 `reset(seed, options)` (:410-424) / `step(action_dict)` (:375-408) signatures, dict-of-agents I/O,
 scalar Python types, `AssertionError` on misuse, and the `env.state = tuple` injection hook the
 reference's tests rely on.  The transition itself is NOT computed here: every step is one launch of
-the HIP kernel on a 1-lane handle (libsoccer_hip.so, batched_step_host).
+the HIP kernel on a 1-lane handle (libsoccer_hip.so, soccer_step_scalar: tuple, actions and uniform go in
+as kernel arguments, the result comes back through a host-mapped record the call polls).
 
 Randomness: like the reference this env owns an `np.random.RandomState` (MT19937, :57-58) and
 draws exactly one uniform per reset and one per step (:395, :414); the uniform is handed to the
 kernel, so for a given seed the trajectories are the reference's own, step for step.
 """
+import ctypes as C
+
 import numpy as np
 
-from .. import spaces
+from .. import _lib, spaces
 from ..core import SoccerBatch
 
 
@@ -38,11 +41,16 @@ class SoccerSimultaneousEnv:
             "Both players cannot have a policy. At least one must be None."
         assert width >= 5, "Width must be at least 5 columns."
         assert height >= 4, "Height must be at least 4 rows."
-        # one lane whose state and I/O staging live in pinned host memory the GPU accesses in place:
-        # a step is one kernel launch + one stream sync, no copies
-        self._batch = SoccerBatch(1, width, height, slip_prob, seed=seed, autoreset=False, device=device,
-                                  host_mapped=True)
-        self._sv = self._batch.host_state_view()
+        # one lane; a step is one kernel launch whose inputs travel as kernel arguments and whose result is
+        # polled from a host-mapped record: no copies, no stream synchronisation
+        self._batch = SoccerBatch(1, width, height, slip_prob, seed=seed, autoreset=False, device=device)
+        self._io = _lib.ScalarIO()
+        self._io_ref = C.byref(self._io)
+        self._h = self._batch.h
+        self._step_scalar = self._batch.lib.soccer_step_scalar
+        self._reset_scalar = self._batch.lib.soccer_reset_scalar
+        self._p_rounded = [np.round(p, 2) for p in self._batch.prob_table]     # info['p'] (:405), per prob_code
+        self._max_t = self._batch.max_steps
         # single-agent mode: the fixed side's policy lives on the device and is looked up by the kernel
         if player_a_policy is not None:
             self._batch.set_policy('player_a', player_a_policy)
@@ -162,30 +170,19 @@ class SoccerSimultaneousEnv:
     def _observation_to_state(self, observation):
         return self._reverse_state_space[observation]
 
-    def _push_state(self):
-        """`env.state = tuple` (and env.timestep) set by the caller is what the next step starts from
-        (tests/test_deterministic_soccer_simultaneous_env.py:43): the host mirror is copied to the lane."""
-        st = tuple(int(x) for x in self.state)
-        if st == self.TERMINAL_STATE or (st not in self.state_space and st not in self.goal_states):
-            raise KeyError(st)                      # P_readable[self.state] in the reference (:394)
-        sv = self._sv
-        sv[0, 0], sv[1, 0], sv[2, 0], sv[3, 0] = st[0], st[1], st[2], st[3]
-        sv[4, 0] = st[4]                                # needs_reset bit cleared
-        sv[5, 0] = min(max(int(self.timestep), 0), self._batch.max_steps)
-
-    def _pull_state(self):
-        sv = self._sv
-        self.state = (int(sv[0, 0]), int(sv[1, 0]), int(sv[2, 0]), int(sv[3, 0]), int(sv[4, 0]) & 1)
-
     def reset(self, seed=None, options=None):
         if seed is not None:
             self.np_random.seed(seed)
-        u = self.np_random.random()                  # one uniform per reset (:414)
-        obs = self._batch.reset_host(u_reset=[u])
-        self._pull_state()
-        p = 1.0 / len(self.isd)
-        self.observations = {a: int(obs[0]) for a in self.return_agent}
-        infos = {a: {"p": np.round(p, 2)} for a in self.return_agent}
+        io = self._io
+        io.u_reset = self.np_random.random()         # one uniform per reset (:414)
+        rc = self._reset_scalar(self._h, self._io_ref)
+        if rc:
+            _lib.check(self._batch.lib, self._h, rc)
+        self.state = (io.row_a, io.col_a, io.row_b, io.col_b, io.poss)
+        p = np.round(1.0 / len(self.isd), 2)
+        obs = io.obs
+        self.observations = {a: obs for a in self.return_agent}
+        infos = {a: {"p": p} for a in self.return_agent}
         self.lastaction = None
         self.needs_reset = False
         self.timestep = 0
@@ -197,34 +194,52 @@ class SoccerSimultaneousEnv:
         assert len(action) == 1 or len(action) == 2, "Action must be a dictionary of length 1 or 2"
         assert self.player_a_policy is not None or 'player_a' in action, "A policy for player_a must be provided"
         assert self.player_b_policy is not None or 'player_b' in action, "A policy for player_b must be provided"
+        io = self._io
         if self.multiagent:
             assert len(action) == 2, "Action must be a dictionary of length 2 for multiagent case"
             assert 'player_a' in action and 'player_b' in action, "Action must contain both 'player_a' and 'player_b'"
+            aa, ab = int(action['player_a']), int(action['player_b'])
         else:
             assert len(action) == 1, "Action must be a dictionary of length 1 for single agent case"
             assert 'player_a' in action or 'player_b' in action, "Action must contain either 'player_a' or 'player_b'"
-        self._push_state()
-        # the fixed side's action is looked up by the kernel from the current observation (:187-188)
-        aa = None if self.player_a_policy is not None else [int(action['player_a'])]
-        ab = None if self.player_b_policy is not None else [int(action['player_b'])]
-        assert all(x is None or 0 <= x[0] < self.nA for x in (aa, ab)), "actions must be in 0..4"
-        u = self.np_random.random()                  # one uniform per step (:395)
-        out = self._batch.step_host(aa, ab, u_step=[u])
-        self._pull_state()
-        prob = self._batch.prob_table[int(out["prob_code"][0])]
-        reward = float(out["reward"][0])
-        done = bool(out["terminated"][0])
-        self.observations = {a: int(out["obs"][0]) for a in self.return_agent}
+            # the fixed side's action is looked up by the kernel from the current observation (:187-188)
+            aa = 0 if self.player_a_policy is not None else int(action['player_a'])
+            ab = 0 if self.player_b_policy is not None else int(action['player_b'])
+        assert 0 <= aa < 5 and 0 <= ab < 5, "actions must be in 0..4"
+        # `env.state = tuple` (and env.timestep) set by the caller is what the step starts from
+        # (tests/test_deterministic_soccer_simultaneous_env.py:43): the host mirror travels with the call
+        st = self.state
+        if st not in self.state_space and st not in self.goal_states or st == self.TERMINAL_STATE:
+            raise KeyError(st)                       # P_readable[self.state] in the reference (:394)
+        io.row_a, io.col_a, io.row_b, io.col_b, io.poss = st
+        t = self.timestep
+        io.t = 0 if t < 0 else (t if t < self._max_t else self._max_t)
+        io.needs_reset = 0
+        io.act_a = aa; io.act_b = ab
+        io.u_step = self.np_random.random()          # one uniform per step (:395)
+        rc = self._step_scalar(self._h, self._io_ref)
+        if rc:
+            _lib.check(self._batch.lib, self._h, rc)
+        self.state = (io.row_a, io.col_a, io.row_b, io.col_b, io.poss)
+        reward = float(io.reward)
+        done = bool(io.terminated)
+        obs = io.obs
         self.lastaction = action
-        self.timestep += 1
+        self.timestep = t = t + 1
+        trunc = t >= 100
+        p = self._p_rounded[io.prob_code]
         if self.multiagent:
+            self.observations = {'player_a': obs, 'player_b': obs}
             rewards = {'player_a': reward, 'player_b': reward * -1}
+            dones = {'player_a': done, 'player_b': done}
+            truncateds = {'player_a': trunc, 'player_b': trunc}
+            infos = {'player_a': {"p": p}, 'player_b': {"p": p}}
         else:                                        # learner-B tables store the flipped sign (:243-244)
-            rewards = {a: (reward if a == 'player_a' else -1 * reward) for a in self.return_agent}
-        dones = {a: done for a in self.return_agent}
-        truncateds = {a: self.timestep >= 100 for a in self.return_agent}
-        infos = {a: {"p": np.round(prob, 2)} for a in self.return_agent}
-        self.needs_reset = any(dones.values()) or any(truncateds.values())
+            a = self.return_agent[0]
+            self.observations = {a: obs}
+            rewards = {a: reward if a == 'player_a' else -1 * reward}
+            dones = {a: done}; truncateds = {a: trunc}; infos = {a: {"p": p}}
+        self.needs_reset = done or trunc
         return self.observations, rewards, dones, truncateds, infos
 
     def render(self):

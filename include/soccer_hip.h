@@ -197,6 +197,32 @@ int batched_reset_staged(soccer_handle* h, uint32_t inputs);
  * learner-B host negates them as the reference's table does (:243-244). */
 int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_host, int32_t n_states);
 
+/* ---- one environment, lowest latency (the single-env facade; reference :375-424) --------- */
+/* For handles with n_lanes == 1.  The current tuple, the actions and the uniform go in BY VALUE (kernel
+ * arguments), the result comes back through a host-mapped record that the kernel writes with one 16-byte
+ * store and the call polls: the GPU reads no host memory and the host enters no stream synchronisation
+ * (~2x lower latency than batched_step_host on a mapped handle, tools/latency_lab.hip).
+ * soccer_step_scalar: in  = row_a..col_b, poss, t, act_a, act_b (ignored for a side with a fixed policy),
+ *                           u_step, u_reset (used only with SOCCER_F_AUTORESET);
+ *                     out = the next tuple / poss / t / needs_reset in the same fields, obs, reward (player A's),
+ *                           terminated, truncated, prob_code.  needs_reset != 0 on input is the reference's
+ *                           "Please reset the environment before taking a step" (SOCCER_E_INVALID, :376);
+ *                           tuples outside the pitch or unreachable are SOCCER_E_INVALID.
+ * soccer_reset_scalar: in = u_reset (the ISD draw, :414); out = tuple, poss, t = 0, obs.
+ * Both consume one tick and leave the lane's resident state equal to the returned one. */
+typedef struct soccer_scalar_io {
+    int8_t row_a, col_a, row_b, col_b;
+    uint8_t poss, needs_reset, t;
+    int8_t act_a, act_b;
+    int8_t reward;
+    uint8_t terminated, truncated, prob_code;
+    uint8_t pad_;
+    uint16_t obs;
+    double u_step, u_reset;
+} soccer_scalar_io;
+int soccer_step_scalar(soccer_handle* h, soccer_scalar_io* io);
+int soccer_reset_scalar(soccer_handle* h, soccer_scalar_io* io);
+
 /* SOCCER_F_HOST_MAPPED handles only: HOST address of the six state streams (row_a, col_a, row_b, col_b,
  * poss|needs_reset<<1, t; `stride` bytes apart).  Valid to read/write whenever the stream is idle
  * (after a *_host call or soccer_sync); writes bypass the tuple validation of soccer_set_state. */

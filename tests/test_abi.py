@@ -42,6 +42,8 @@ int main(void) {
            offsetof(soccer_config, flags), offsetof(soccer_config, stream));
     printf("%zu %zu %zu\\n", offsetof(soccer_rollout_args, act_stride), offsetof(soccer_rollout_args, out_stride),
            offsetof(soccer_rollout_args, mix_a));
+    printf("%zu %zu %zu %zu %zu\\n", sizeof(soccer_scalar_io), offsetof(soccer_scalar_io, act_a), offsetof(soccer_scalar_io, obs),
+           offsetof(soccer_scalar_io, u_step), offsetof(soccer_scalar_io, u_reset));
     return 0;
 }
 """)
@@ -49,10 +51,11 @@ int main(void) {
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     got = [int(x) for x in out]
-    Cfg, St, Ro = _lib.Config, _lib.StepArgs, _lib.RolloutArgs
+    Cfg, St, Ro, Sc = _lib.Config, _lib.StepArgs, _lib.RolloutArgs, _lib.ScalarIO
     assert got == [C.sizeof(Cfg), C.sizeof(St), C.sizeof(Ro),
                    Cfg.slip_prob.offset, Cfg.seed.offset, Cfg.flags.offset, Cfg.stream.offset,
-                   Ro.act_stride.offset, Ro.out_stride.offset, Ro.mix_a.offset]
+                   Ro.act_stride.offset, Ro.out_stride.offset, Ro.mix_a.offset,
+                   C.sizeof(Sc), Sc.act_a.offset, Sc.obs.offset, Sc.u_step.offset, Sc.u_reset.offset]
 
 
 @pytest.mark.parametrize("kw,msg", [

@@ -237,6 +237,77 @@ def test_slip_thresholds_hit_exactly_and_within_rounding_distance(slip, width, h
     b.close()
 
 
+@pytest.mark.parametrize("width,height,slip,learner", [(5, 4, 0.0, None), (5, 4, 0.2, None), (7, 5, 0.3, None),
+                                                       (5, 4, 0.2, "player_a"), (5, 4, 0.2, "player_b")])
+def test_scalar_step_and_reset_match_oracle(width, height, slip, learner):
+    """soccer_step_scalar / soccer_reset_scalar (inputs as kernel arguments, result polled from a mapped
+    record): every field against the oracle's one-lane step from random reachable tuples (live and goal),
+    with and without a fixed policy; the lane's resident state follows."""
+    rng = np.random.default_rng(3)
+    o = Oracle(width, height, slip, n=1)
+    lut, kind, *_ = o.tables()
+    W = width + 2
+    b = SoccerBatch(1, width, height, slip)
+    policy = None
+    if learner:
+        policy = rng.integers(0, 5, b.nS).astype(np.int8)
+        b.set_policy("player_b" if learner == "player_a" else "player_a", policy)
+    reach = np.flatnonzero(kind != 0)
+    for f in rng.choice(reach, 400):
+        p_ = f & 1; r = f >> 1; yb = r % W; r //= W; xb = r % height; r //= height; ya = r % W; xa = r // W
+        st = (int(xa), int(ya), int(xb), int(yb), int(p_))
+        aa, ab = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        t = int(rng.choice([0, 5, 98, 99]))
+        u = float(rng.random())
+        s_now = 0 if kind[f] == 2 else int(lut[f])
+        if learner == "player_a": ab = int(policy[s_now])
+        if learner == "player_b": aa = int(policy[s_now])
+        o.set_state([st[0]], [st[1]], [st[2]], [st[3]], [st[4]], t=t, needs_reset=np.zeros(1, np.uint8))
+        want = o.step(np.array([aa], np.int8), np.array([ab], np.int8), u_step=np.array([u]))
+        got = b.step_scalar(st, None if learner == "player_b" else aa, None if learner == "player_a" else ab, u, t=t)
+        for k in ("obs", "reward", "terminated", "truncated", "prob_code"):
+            assert got[k] == int(want[k][0]), (k, st, aa, ab, u)
+        assert got["state"] == (o.row_a[0], o.col_a[0], o.row_b[0], o.col_b[0], o.poss[0] & 1)
+        assert got["t"] == o.t[0] and got["needs_reset"] == (o.poss[0] >> 1)
+        assert_state_equal(b, o)
+    for u in (0.0, 0.24, 0.25, 0.5, 0.74, 0.75, 0.999999):
+        want = o.reset(u_reset=np.array([u]))
+        got = b.reset_scalar(u)
+        assert got["obs"] == int(want[0]) and got["t"] == 0 and got["needs_reset"] == 0
+        assert_state_equal(b, o)
+    # misuse and validation happen on the host, before any launch
+    with pytest.raises(AssertionError, match="outside the pitch"):
+        b.step_scalar((height, 1, 0, 2, 0), 0, 0, 0.5)
+    with pytest.raises(AssertionError, match="unreachable"):
+        b.step_scalar((0, 1, 0, 1, 0), 0, 0, 0.5)
+    if not learner:
+        with pytest.raises(AssertionError, match="actions"):
+            b.step_scalar((0, 1, 0, 2, 0), 5, 0, 0.5)
+    b2 = SoccerBatch(2, width, height, slip)
+    with pytest.raises(AssertionError, match="n_lanes == 1"):
+        b2.step_scalar((0, 1, 0, 2, 0), 0, 0, 0.5)
+    b.close(); b2.close()
+
+
+def test_host_mapped_handle_matches_a_device_resident_one():
+    """SOCCER_F_HOST_MAPPED: state and staging live in pinned host memory the GPU accesses in place."""
+    n = 1000
+    rng = np.random.default_rng(8)
+    bm = SoccerBatch(n, 5, 4, 0.2, seed=4, autoreset=True, host_mapped=True)
+    bd = SoccerBatch(n, 5, 4, 0.2, seed=4, autoreset=True)
+    np.testing.assert_array_equal(bm.reset_host(), bd.reset_host())
+    for _ in range(120):
+        a, c = rng.integers(0, 5, n, dtype=np.int8), rng.integers(0, 5, n, dtype=np.int8)
+        g1, g2 = bm.step_host(a, c), bd.step_host(a, c)
+        for k in ("obs", "reward", "terminated", "truncated", "prob_code", "final_obs"):
+            np.testing.assert_array_equal(g1[k], g2[k], err_msg=k)
+    sv = bm.host_state_view()
+    s = bd.get_state()
+    np.testing.assert_array_equal(sv[0, :n].view(np.int8), s["row_a"])
+    np.testing.assert_array_equal(sv[5, :n], s["t"])
+    bm.close(); bd.close()
+
+
 @pytest.mark.parametrize("learner", ["player_a", "player_b"])
 def test_single_agent_tables_every_row(learner):
     """Fixed-opponent mode against the REFERENCE's single-agent transition table (all ~43 000 rows):
