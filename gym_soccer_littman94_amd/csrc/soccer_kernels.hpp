@@ -255,9 +255,14 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         const uint32_t k = R.kind == K_COIN ? (d.top2 >> 1) : d.top2;
         sel = pick(A, B, p, R, k);
     } else {
-        constexpr int VA[9] = {0, 0, 0, 1, 2, 1, 1, 2, 2};
-        constexpr int VB[9] = {0, 1, 2, 0, 0, 1, 2, 1, 2};
-        constexpr int CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+        // VA / VB / CLS of the nine combinations (:209-223), 2 bits each: A's move variant, B's move variant and the
+        // weight class (c0..c3).  Bit fields, not arrays: a loop the compiler leaves rolled must not turn them
+        // (or the by-value weights P.w) into scratch.
+        constexpr uint32_t VA2 = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
+        constexpr uint32_t VB2 = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
+        constexpr uint32_t CL2 = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
+        const double w0 = P.w[0], w1 = P.w[1], w2 = P.w[2], w3 = P.w[3];
+#define SOCCER_WEIGHT_OF(cl) (((cl) & 2u) ? (((cl) & 1u) ? w3 : w2) : (((cl) & 1u) ? w1 : w0))
         // each player has only three distinct moves (intended + two orthogonals): 6 table reads serve
         // all nine combinations
         uint32_t cellA[3], cellB[3];
@@ -285,15 +290,12 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         near_thr |= idx >= P.nb;
         uint32_t sel_c = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull), sel_k = 0u;
         {
-            constexpr uint32_t VA2f = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
-            constexpr uint32_t VB2f = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
-            constexpr uint32_t CL2f = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
-            const uint32_t va = (VA2f >> (2u * sel_c)) & 3u, vb = (VB2f >> (2u * sel_c)) & 3u, cl = (CL2f >> (2u * sel_c)) & 3u;
+            const uint32_t va = (VA2 >> (2u * sel_c)) & 3u, vb = (VB2 >> (2u * sel_c)) & 3u, cl = (CL2 >> (2u * sel_c)) & 3u;
             const uint32_t cA = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
             const uint32_t cB = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
             const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cA, cB, aa, ab).kind;
             const uint32_t n = kind == K_COIN ? 2u : (kind == K_FOUR ? 4u : 1u);
-            const double wq = cl & 2u ? (cl & 1u ? P.w[3] : P.w[2]) : (cl & 1u ? P.w[1] : P.w[0]);
+            const double wq = SOCCER_WEIGHT_OF(cl);
             const double q = wq * (n == 1u ? 1.0 : (n == 2u ? 0.5 : 0.25));
             const double t1 = S + q, t2 = t1 + q, t3 = t2 + q;
             sel_k = (((n > 1u) & (d.u >= t1)) ? 1u : 0u) + (((n > 2u) & (d.u >= t2)) ? 1u : 0u) +
@@ -311,10 +313,14 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
             int first_c = -1;                                           // wave-uniform (weights are)
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-                const double wgt = P.w[CLS[c]];
+                const uint32_t cl_c = (CL2 >> (2 * c)) & 3u;
+                const double wgt = SOCCER_WEIGHT_OF(cl_c);
                 if (wgt == 0.0) continue;                               // uniform branch (:226-227)
                 if (first_c < 0) first_c = c;
-                const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cellA[VA[c]], cellB[VB[c]], aa, ab).kind;
+                const uint32_t va_c = (VA2 >> (2 * c)) & 3u, vb_c = (VB2 >> (2 * c)) & 3u;
+                const uint32_t cA_c = va_c == 0u ? cellA[0] : (va_c == 1u ? cellA[1] : cellA[2]);
+                const uint32_t cB_c = vb_c == 0u ? cellB[0] : (vb_c == 1u ? cellB[1] : cellB[2]);
+                const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cA_c, cB_c, aa, ab).kind;
                 const uint32_t n = kind == K_COIN ? 2u : (kind == K_FOUR ? 4u : 1u);
                 const double q = wgt * (n == 1u ? 1.0 : (n == 2u ? 0.5 : 0.25));   // :241
                 const double a1 = acc + q, a2 = a1 + q, a3 = a2 + q, a4 = a3 + q;   // sequential cumsum
@@ -328,10 +334,8 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
             }
             if (!found) { sel_c = (uint32_t)(first_c < 0 ? 0 : first_c); sel_k = 0u; }   // argmax of all-False is 0
         }
-        // VA / VB / CLS of the selected combination, 2 bits each
-        constexpr uint32_t VA2 = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
-        constexpr uint32_t VB2 = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
-        constexpr uint32_t CL2 = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
+#undef SOCCER_WEIGHT_OF
+        // the selected combination
         const uint32_t va = (VA2 >> (2u * sel_c)) & 3u, vb = (VB2 >> (2u * sel_c)) & 3u;
         cls = (CL2 >> (2u * sel_c)) & 3u;
         const uint32_t sA_ = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
@@ -708,12 +712,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
 // Same lane loop as step_kernel; kept separate because a launch starts with a cold instruction cache
 // and every instruction that is not fetched counts (-0.4 us per launch against step_kernel<..., LEAN>).
 template <bool SLIP>
-__global__ __launch_bounds__(kBlock) void step_kernel_hot(const KernelParams P, const StepIO IO) {
-    const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    if ((g << 2) >= P.n) return;                                    // P.n is a multiple of 4 here
+__device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& IO, unsigned long long g, unsigned long long tick) {
     const unsigned long long i0 = P.first + (g << 2);
-    const unsigned long long tick = *P.tick_in;                     // scalar load
-    if (P.tick_out) publish_tick(P, tick, 1ull);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
     const uint8_t* sp = P.state;
     const uint32_t ra = *reinterpret_cast<const uint32_t*>(sp + i0);
@@ -756,6 +756,15 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(const KernelParams P, 
     if (IO.terminated) *reinterpret_cast<uint32_t*>(IO.terminated + i0) = o_term;
     if (IO.truncated) *reinterpret_cast<uint32_t*>(IO.truncated + i0) = o_trunc;
     if (mis) *P.misuse = 1u;
+}
+
+template <bool SLIP>
+__global__ __launch_bounds__(kBlock) void step_kernel_hot(const KernelParams P, const StepIO IO) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if ((g << 2) >= P.n) return;                                    // P.n is a multiple of 4 here
+    const unsigned long long tick = *P.tick_in;                     // scalar load
+    if (P.tick_out) publish_tick(P, tick, 1ull);
+    hot_group<SLIP>(P, IO, g, tick);
 }
 
 // =================================================================================================

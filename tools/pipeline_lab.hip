@@ -1,0 +1,103 @@
+// pipeline_lab.hip — can consecutive batched_step launches overlap?  (diagnostic; not shipped)
+// Consecutive steps depend on each other only lane by lane, i.e. workgroup j of step k+1 needs workgroup j
+// of step k, nothing else.  Variant "chain": every workgroup waits on a per-workgroup counter its
+// predecessor publishes, and the launches carry hipExtAnyOrderLaunch (no barrier between the dispatches),
+// so step k+1's workgroups start while step k's tail is still running.  Every wait is bounded.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I gym_soccer_littman94_amd/csrc tools/pipeline_lab.hip -o build/pipeline_lab
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "soccer_kernels.hpp"
+#include "soccer_rules.hpp"
+using namespace soccer;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+template <bool SLIP>
+__global__ __launch_bounds__(kBlock) void k_plain(const KernelParams P, const StepIO IO, unsigned long long tick) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if ((g << 2) >= P.n) return;
+    hot_group<SLIP>(P, IO, g, tick);
+}
+
+// STRIDE: uint32 words between consecutive workgroups' counters (1 = packed, 16 = one 64-byte line each)
+template <bool SLIP, int STRIDE>
+__global__ __launch_bounds__(kBlock) void k_chain(const KernelParams P, const StepIO IO, unsigned long long tick,
+                                                  uint32_t* done, uint32_t seq, uint32_t* err) {
+    uint32_t* mine = done + (size_t)blockIdx.x * STRIDE;
+    if (threadIdx.x == 0) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 17)) { *err = 1u; break; }               // bounded: never hang the GPU
+        }
+    }
+    __syncthreads();
+    const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if ((g << 2) < P.n) hot_group<SLIP>(P, IO, g, tick);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(mine, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int main(int argc, char** argv) {
+    const size_t N = 1 << 20;
+    const int K = argc > 1 ? atoi(argv[1]) : 1000;
+    Rules R; R.build(5, 4);
+    KernelParams P{};
+    uint8_t* d_state; CK(hipMalloc(&d_state, 6 * N));
+    uint16_t* d_lut; uint32_t* d_nc; uint32_t* d_isd; unsigned int* d_mis;
+    CK(hipMalloc(&d_lut, R.lut.size() * 2)); CK(hipMemcpy(d_lut, R.lut.data(), R.lut.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_nc, R.next_cell.size() * 4)); CK(hipMemcpy(d_nc, R.next_cell.data(), R.next_cell.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_isd, 64)); CK(hipMemcpy(d_isd, R.isd_words, 64, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_mis, 128)); CK(hipMemset(d_mis, 0, 128));
+    P.state = d_state; P.state_stride = N; P.lut = d_lut; P.lut_len = (int)R.lut.size(); P.next_cell = d_nc; P.isd = d_isd;
+    P.key0 = 1; P.key1 = 2; P.lane_offset = 0; P.misuse = d_mis; P.first = 0; P.n = N; P.W = R.W; P.HW = R.H * R.W; P.HW5 = 5 * R.H * R.W;
+    P.nc_len = (int)R.next_cell.size(); P.max_steps = 100; P.autoreset = 1; P.step_stats = 0; P.isd_shift = 0;
+    P.w[0] = 1; P.w[1] = P.w[2] = P.w[3] = 0; P.nb = 1; P.act_pack = 0; for (int c = 0; c < 9; ++c) P.B[c] = c ? __builtin_inf() : 1.0;
+    const int T = 64;
+    int8_t* d_act; CK(hipMalloc(&d_act, (size_t)T * 2 * N));
+    { std::vector<int8_t> h((size_t)T * 2 * N); srand(7); for (auto& x : h) x = rand() % 5; CK(hipMemcpy(d_act, h.data(), h.size(), hipMemcpyHostToDevice)); }
+    uint16_t* d_obs; int8_t* d_rew; uint8_t* d_term; uint8_t* d_trunc;
+    CK(hipMalloc(&d_obs, N * 2)); CK(hipMalloc(&d_rew, N)); CK(hipMalloc(&d_term, N)); CK(hipMalloc(&d_trunc, N));
+    uint32_t* d_done; CK(hipMalloc(&d_done, 1024 * 16 * 4)); uint32_t* d_err; CK(hipMalloc(&d_err, 4)); CK(hipMemset(d_err, 0, 4));
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto io_for = [&](int k) { StepIO io{}; io.act_a = d_act + (size_t)(k % T) * 2 * N; io.act_b = io.act_a + N;
+        io.obs = d_obs; io.reward = d_rew; io.terminated = d_term; io.truncated = d_trunc; return io; };
+    auto init = [&] {
+        CK(hipMemset(d_state, 1, N)); CK(hipMemset(d_state + N, 2, N)); CK(hipMemset(d_state + 2 * N, 2, N));
+        CK(hipMemset(d_state + 3 * N, 4, N)); CK(hipMemset(d_state + 4 * N, 0, N)); CK(hipMemset(d_state + 5 * N, 0, N));
+        CK(hipMemset(d_done, 0, 1024 * 16 * 4)); CK(hipDeviceSynchronize());
+    };
+    std::vector<uint8_t> ref(6 * N + 2 * N), got(6 * N + 2 * N);
+    auto snapshot = [&](std::vector<uint8_t>& v) { CK(hipMemcpy(v.data(), d_state, 6 * N, hipMemcpyDeviceToHost)); CK(hipMemcpy(v.data() + 6 * N, d_obs, 2 * N, hipMemcpyDeviceToHost)); };
+    auto timed = [&](const char* name, auto launch, std::vector<uint8_t>* out) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            init();
+            CK(hipEventRecord(e0, st));
+            for (int k = 0; k < K; ++k) launch(k);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        if (out) snapshot(*out);
+        uint32_t err; CK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+        printf("%-46s %7.2f us/step%s\n", name, best * 1e3f / K, err ? "   [WAIT GAVE UP]" : "");
+        CK(hipMemset(d_err, 0, 4));
+    };
+    timed("plain, normal launches", [&](int k) { hipLaunchKernelGGL(k_plain<false>, dim3(1024), dim3(256), 0, st, P, io_for(k), (unsigned long long)k); }, &ref);
+    timed("chain (packed flags), normal launches", [&](int k) { hipLaunchKernelGGL((k_chain<false, 1>), dim3(1024), dim3(256), 0, st, P, io_for(k), (unsigned long long)k, d_done, (uint32_t)k, d_err); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("chain (packed flags), any-order launches", [&](int k) { hipExtLaunchKernelGGL((k_chain<false, 1>), dim3(1024), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, P, io_for(k), (unsigned long long)k, d_done, (uint32_t)k, d_err); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("chain (64 B per flag), any-order launches", [&](int k) { hipExtLaunchKernelGGL((k_chain<false, 16>), dim3(1024), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, P, io_for(k), (unsigned long long)k, d_done, (uint32_t)k, d_err); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("plain, normal launches (again)", [&](int k) { hipLaunchKernelGGL(k_plain<false>, dim3(1024), dim3(256), 0, st, P, io_for(k), (unsigned long long)k); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    return 0;
+}
