@@ -56,6 +56,9 @@ struct soccer_handle {
     uint64_t capture_ticks = 0;
     int capture_calls = 0;
     int capture_start_slot = 0;
+    // LDS transition-table rollout (slip 0, table fits the LDS): see rollout_table_kernel
+    uint32_t* d_trans = nullptr; uint16_t* d_code_lut = nullptr; uint32_t* d_code_tuple = nullptr;
+    TransTables TT{}; bool table_ok = false; size_t table_smem = 0; int n_cu = 256;
     uint4* rec_host = nullptr; uint4* rec_dev = nullptr; uint32_t rec_seq = 0;   // soccer_step_scalar's mapped result record
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
@@ -99,7 +102,8 @@ static void free_handle(soccer_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->d_misuse, h->stage_dev};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->d_misuse, h->stage_dev,
+                    h->d_trans, h->d_code_lut, h->d_code_tuple};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -123,6 +127,58 @@ static hipError_t raise_smem_limit(size_t bytes) {
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<E, SLIP, LUT_LDS, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// The (state code, joint action) -> outcome table of rollout_table_kernel, built from the host copies of the
+// move/bounds table and the same classify() the kernels run.  Returns "" or an internal-error message;
+// `fits` says whether codes fit 14 bits (else the table path is simply not used).
+static std::string build_transition_table(const Rules& R, std::vector<uint32_t>& trans, std::vector<uint16_t>& code_lut,
+                                          std::vector<uint32_t>& code_tuple, bool& fits) {
+    const int H = R.H, W = R.W, HW = H * W, nS = R.nS;
+    const size_t T = R.lut.size();
+    code_lut.assign(T, 0xFFFF);
+    int nG = 0;
+    for (size_t f = 0; f < T; ++f) if (R.kind[f] == 2) ++nG;
+    fits = nS + nG <= 0x3fff;
+    if (!fits) return "";
+    code_tuple.assign((size_t)nS + nG, 0);
+    int gid = 0;
+    for (size_t f = 0; f < T; ++f) {
+        if (R.kind[f] == 0) continue;
+        const uint32_t code = R.kind[f] == 2 ? (uint32_t)(nS + gid++) : R.lut[f];
+        const uint32_t p = f & 1, cb = (f >> 1) % HW, ca = (f >> 1) / HW;
+        code_lut[f] = (uint16_t)code;
+        code_tuple[code] = (ca / W) | ((ca % W) << 4) | ((cb / W) << 8) | ((cb % W) << 12) | (p << 16);
+    }
+    auto pos_of = [&](uint32_t cell) { return cell | ((((cell / W) << 8) | (cell % W)) << 16); };
+    auto code_of = [&](uint32_t A, uint32_t B, uint32_t p) { return (uint32_t)code_lut[((size_t)(A & 0xffffu) * HW + (B & 0xffffu)) * 2 + p]; };
+    trans.assign((size_t)nS * 25, 0);
+    for (size_t f = 0; f < T; ++f) {
+        if (R.kind[f] != 1) continue;
+        const uint32_t p = f & 1, cellB = (f >> 1) % HW, cellA = (f >> 1) / HW;
+        const uint32_t A = pos_of(cellA), B = pos_of(cellB), s = R.lut[f];
+        for (uint32_t aa = 0; aa < 5; ++aa) for (uint32_t ab = 0; ab < 5; ++ab) {
+            const uint32_t nA = R.next_cell[((p ^ 1u) * HW + cellA) * 5 + aa], nB = R.next_cell[(p * HW + cellB) * 5 + ab];
+            const Resolved r = classify(A, B, nA, nB, aa, ab);
+            uint32_t n0 = 0, n1 = 0, plus = 0;
+            if (r.kind == K_MOVE) {
+                n0 = code_of(nA, nB, p);
+                if (n0 >= (uint32_t)nS && n0 != 0xFFFF) plus = (((p ? nB : nA) >> 16) & 0xffu) == (uint32_t)(W - 1) ? 1u : 0u;   // :94-98
+            } else if (r.kind == K_FLIP) {
+                n0 = code_of(A, B, p ^ 1u);
+            } else if (r.kind == K_COIN) {
+                n0 = code_of(A, B, 0);
+                if (code_of(A, B, 1) != n0 + 1) return "internal error: possession codes are not consecutive";
+            } else {
+                n0 = code_of(A, nB, 0); n1 = code_of(nA, B, 0);
+                if (code_of(A, nB, 1) != n0 + 1 || code_of(nA, B, 1) != n1 + 1) return "internal error: possession codes are not consecutive";
+                if (n1 >= (uint32_t)nS) return "internal error: a four-way tie reaches a goal tuple";
+            }
+            if (n0 == 0xFFFF || (r.kind != K_MOVE && n0 >= (uint32_t)nS)) return "internal error: a transition leaves the reachable tuples";
+            trans[(size_t)s * 25 + aa * 5 + ab] = n0 | (n1 << 14) | (r.kind << 28) | (plus << 30);
+        }
+    }
+    return "";
 }
 
 extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
@@ -265,6 +321,30 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
     h->grid_cap = prop.multiProcessorCount * 8;
+    h->n_cu = prop.multiProcessorCount;
+    if (!h->slip) {     // LDS transition table for batched_rollout, when it fits
+        std::vector<uint32_t> trans, code_tuple; std::vector<uint16_t> code_lut; bool fits = false;
+        const std::string terr = build_transition_table(R, trans, code_lut, code_tuple, fits);
+        if (!terr.empty()) { free_handle(h); return fail(nullptr, SOCCER_E_INVALID, "%s", terr.c_str()); }
+        const size_t smem = (trans.size() + kIsdWords) * sizeof(uint32_t);
+        if (fits && smem <= 150 * 1024) {
+            CREATE_TRY(hipMalloc(&h->d_trans, trans.size() * 4 + 16));
+            CREATE_TRY(hipMemcpy(h->d_trans, trans.data(), trans.size() * 4, hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc(&h->d_code_lut, code_lut.size() * 2));
+            CREATE_TRY(hipMemcpy(h->d_code_lut, code_lut.data(), code_lut.size() * 2, hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc(&h->d_code_tuple, code_tuple.size() * 4));
+            CREATE_TRY(hipMemcpy(h->d_code_tuple, code_tuple.data(), code_tuple.size() * 4, hipMemcpyHostToDevice));
+            h->TT = TransTables{h->d_trans, h->d_code_lut, h->d_code_tuple, R.nS, (int32_t)code_tuple.size()};
+            h->table_smem = smem;
+            hipError_t se = hipSuccess;
+#define RAISE_T(EV, DV) if (se == hipSuccess) se = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_table_kernel<EV, DV>), \
+                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            RAISE_T(1, false) RAISE_T(1, true) RAISE_T(4, false) RAISE_T(4, true)
+#undef RAISE_T
+            CREATE_TRY(se);
+            h->table_ok = true;
+        }
+    }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     *out = h;
@@ -461,7 +541,18 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                      (long long)a->act_stride, a->obs ? a->obs + oo : nullptr, a->reward ? a->reward + oo : nullptr,
                      a->terminated ? a->terminated + oo : nullptr, a->truncated ? a->truncated + oo : nullptr,
                      (long long)a->out_stride, a->return_sum, a->episode_count};
-        switch (E) {
+        if (h->table_ok) {      // slip 0 and the transition table fits the LDS: one gather per env-step
+            const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
+            const int ET = E >= 4 ? 4 : 1;
+            const uint64_t groups = (P.n + ET - 1) / ET;
+            uint64_t blocks = (groups + kTblBlock - 1) / kTblBlock;
+            if (blocks > (uint64_t)h->n_cu) blocks = h->n_cu;
+            const dim3 g((unsigned)blocks), bl(kTblBlock);
+            if (ET == 4) { if (dyn) hipLaunchKernelGGL((rollout_table_kernel<4, true>), g, bl, h->table_smem, h->stream, P, io, h->TT);
+                           else hipLaunchKernelGGL((rollout_table_kernel<4, false>), g, bl, h->table_smem, h->stream, P, io, h->TT); }
+            else { if (dyn) hipLaunchKernelGGL((rollout_table_kernel<1, true>), g, bl, h->table_smem, h->stream, P, io, h->TT);
+                   else hipLaunchKernelGGL((rollout_table_kernel<1, false>), g, bl, h->table_smem, h->stream, P, io, h->TT); }
+        } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;
             case 4: launch_rollout<4>(h, P, io); break;
             default: launch_rollout<1>(h, P, io); break;

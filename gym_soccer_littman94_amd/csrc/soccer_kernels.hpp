@@ -211,7 +211,7 @@ __device__ __forceinline__ uint32_t moved(const Tables& T, const KernelParams& P
 
 // _get_next_state (:296-362) for a live tuple, given the cells nA / nB the two (possibly slipped) moves
 // reach.  aa/ab are the ORIGINAL actions: the reference's NOOP tests use those, not the moves.
-__device__ __forceinline__ Resolved classify(uint32_t A, uint32_t B, uint32_t nA, uint32_t nB, uint32_t aa, uint32_t ab) {
+__host__ __device__ __forceinline__ Resolved classify(uint32_t A, uint32_t B, uint32_t nA, uint32_t nB, uint32_t aa, uint32_t ab) {
     const bool e1 = nA == B, e2 = nB == A, sA = nA == A, sB = nB == B;
     const bool swap = e1 & e2;                                                         // :315-322
     const bool stander = (e1 & (ab == 0u)) | (e2 & (aa == 0u));                      // :330-331
@@ -947,6 +947,237 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const KernelParams P, c
         } else {
             for (unsigned long long i = i0; i < P.n; ++i)
                 rollout_group<1, SLIP, DYN>(T, P, IO, i, tick0, hist, any_misuse);
+        }
+    }
+    if (any_misuse) *P.misuse = 1u;
+    hist.flush(P);
+}
+
+// =================================================================================================
+// batched_rollout through an LDS-resident transition table (slip_prob == 0, tables that fit the LDS)
+// =================================================================================================
+// The rule-function rollout above is bound by vector-instruction issue (~110 per env-step).  Here the whole
+// (state, joint action) -> outcome relation of the pitch — what the reference materialises as P (:167-293),
+// 761 x 25 entries of 4 bytes = 76 KB for 5x4 — is staged once per workgroup into the CU's 160 KB LDS and a
+// lane carries its tuple as a STATE CODE: the observation index for live tuples, nS + goal id for goal
+// tuples.  A step is then one LDS gather plus ~20 selects.  Entry layout:
+//   bits 0-13 n0, bits 14-27 n1, bits 28-29 kind, bit 30 reward is +1 (else -1) when n0 is a goal code
+//   K_MOVE: next code n0 (goal code = scored)      K_FLIP: n0 = same cells, possession flipped
+//   K_COIN: n0 + k, k = possession drawn           K_FOUR: (k < 2 ? n0 : n1) + (k & 1)
+// (the p = 0 / p = 1 codes of one pair of cells are consecutive).  The table is built on the host from the
+// same classify() the kernels use (soccer_hip.hip, build_transition_table) and every rollout test runs
+// through it.
+struct TransTables {
+    const uint32_t* trans;        // [nS * 25]
+    const uint16_t* code_lut;     // [lut_len] tuple -> state code (0xFFFF unreachable)
+    const uint32_t* code_tuple;   // [n_codes] state code -> row_a | col_a << 4 | row_b << 8 | col_b << 12 | poss << 16
+    int32_t nS, n_codes;
+};
+constexpr int kTblBlock = 1024;          // one workgroup per CU shares one copy of the table
+
+// The T steps of one thread's E lanes.  GENERAL = false is the steady state of an auto-resetting handle: no
+// lane is frozen or sits in a goal tuple on entry, so none ever will, and the code for those cases (and the
+// per-lane return / episode accumulators, unless asked for) is compiled out; episode totals come from
+// population counts over the packed output dwords.
+template <int E, bool DYN, bool GENERAL>
+__device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_t* isd, uint32_t nS,
+                                            const KernelParams& P, const RolloutIO& IO,
+                                            unsigned long long i0, unsigned long long tick0,
+                                            uint32_t (&c)[E], uint32_t (&t)[E], uint32_t (&need)[E], int32_t (&acc)[E],
+                                            uint32_t& fin_tot, int32_t& rew_tot, uint32_t& nonzero, bool& any_misuse) {
+    const bool lane_acc = GENERAL || IO.return_sum != nullptr || IO.episode_count != nullptr;   // uniform
+    PackB<E> aa, ab; aa.clear(); ab.clear();
+    const bool sample = DYN && IO.sample_actions;
+    if (!sample) {
+        if (!DYN || IO.act_a) aa.load(IO.act_a, i0);
+        if (!DYN || IO.act_b) ab.load(IO.act_b, i0);
+    }
+    for (int s = 0; s < IO.n_steps; ++s) {
+        const unsigned long long tick = tick0 + (unsigned long long)s;
+        PackB<E> naa = aa, nab = ab;
+        if (!sample && s + 1 < IO.n_steps) {                            // prefetch the next step's actions
+            if (!DYN || IO.act_a) naa.load(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
+            if (!DYN || IO.act_b) nab.load(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
+        }
+        uint32_t words[E], awords[E];
+        lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
+        if (sample) lane_words<E>(P, P.lane_offset + i0, tick, 1u, awords);
+        PackB<E> o_rew, o_term, o_trunc; PackH<E> o_obs;
+        o_rew.clear(); o_term.clear(); o_trunc.clear(); o_obs.clear();
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t top2 = words[j] >> 30, reset2 = words[j] & 3u;
+            const uint32_t cj = c[j], tj = t[j];
+            const bool in_goal = GENERAL && cj >= nS;
+            const uint32_t s_now = in_goal ? 0u : cj;                   // the current observation
+            uint32_t a = aa.get(j), b = ab.get(j);
+            if (sample) {                               // two actions from one 32-bit word, 15 bits each
+                const uint32_t ha = awords[j] & 0x7fffu, hb = (awords[j] >> 16) & 0x7fffu;
+                a = (ha * 5u) >> 15;
+                b = (hb * 5u) >> 15;
+                if (IO.mix_a) {
+                    const uint2 th = *reinterpret_cast<const uint2*>(IO.mix_a + 4u * s_now);
+                    a = (ha >= (th.x & 0xffffu)) + (ha >= (th.x >> 16)) + (ha >= (th.y & 0xffffu)) + (ha >= (th.y >> 16));
+                }
+                if (IO.mix_b) {
+                    const uint2 th = *reinterpret_cast<const uint2*>(IO.mix_b + 4u * s_now);
+                    b = (hb >= (th.x & 0xffffu)) + (hb >= (th.x >> 16)) + (hb >= (th.y & 0xffffu)) + (hb >= (th.y >> 16));
+                }
+            }
+            if (DYN) {
+                if (P.policy_a) a = (uint32_t)(uint8_t)P.policy_a[s_now];
+                if (P.policy_b) b = (uint32_t)(uint8_t)P.policy_b[s_now];
+            }
+            const uint32_t e = trans[mad24(s_now, 25u, mad24(a, 5u, b))];
+            const uint32_t kind = (e >> 28) & 3u;
+            const uint32_t k = kind == K_COIN ? (top2 >> 1) : top2;     // floor(2u) / floor(4u), as lane_step
+            const bool second = (kind == K_FOUR) & (k >= 2u);
+            const uint32_t base = second ? ((e >> 14) & 0x3fffu) : (e & 0x3fffu);
+            uint32_t nc = base + (kind >= K_COIN ? (k & 1u) : 0u);
+            if (GENERAL) nc = in_goal ? cj : nc;                        // goal tuples are absorbing (:300-301)
+            const bool goal_now = nc >= nS;
+            const int32_t reward = (goal_now & !in_goal) ? ((e >> 30) & 1u ? 1 : -1) : 0;
+            const uint32_t tt = tj + 1u;
+            const uint32_t trunc = tt >= (uint32_t)P.max_steps ? 1u : 0u;
+            const uint32_t done = goal_now ? 1u : 0u;
+            const uint32_t nd = done | trunc;
+            uint32_t ob = goal_now ? 0u : nc;
+            uint32_t c2 = nc, t2 = tt, need2 = nd;
+            if (!GENERAL || P.autoreset) {                              // uniform
+                const uint32_t z = isd[4u * (reset2 >> P.isd_shift) + 2u] >> 16;    // ISD entry's observation = its code
+                c2 = nd ? z : nc; t2 = nd ? 0u : tt; need2 = 0u; ob = c2;
+            }
+            if (GENERAL) {
+                const bool frozen = need[j] != 0u;                      // left untouched (:376)
+                any_misuse |= frozen;
+                const uint32_t r_obs = frozen ? s_now : ob;
+                const int32_t r_rew = frozen ? 0 : reward;
+                const uint32_t r_term = frozen ? (in_goal ? 1u : 0u) : done;
+                const uint32_t r_trunc = frozen ? (tj >= (uint32_t)P.max_steps ? 1u : 0u) : trunc;
+                const uint32_t fin = frozen ? 0u : nd;
+                c[j] = frozen ? cj : c2; t[j] = frozen ? tj : t2; need[j] = frozen ? 1u : need2;
+                o_obs.put(j, r_obs); o_rew.put(j, (uint32_t)r_rew & 0xffu); o_term.put(j, r_term); o_trunc.put(j, r_trunc);
+                acc[j] += (r_rew << 16) + (int32_t)fin; nonzero += (uint32_t)r_rew & 1u;
+                fin_tot += fin; rew_tot += r_rew;
+            } else {
+                c[j] = c2; t[j] = t2;
+                o_obs.put(j, ob); o_rew.put(j, (uint32_t)reward & 0xffu); o_term.put(j, done); o_trunc.put(j, trunc);
+                if (lane_acc) acc[j] += (reward << 16) + (int32_t)nd;
+            }
+        }
+        if (!GENERAL) {                     // totals of the E lanes from the packed bytes (0/1 flags, rewards 0x00/0x01/0xff)
+            if constexpr (E == 1) {
+                fin_tot += o_term.b | o_trunc.b; nonzero += o_rew.b & 1u; rew_tot += (int32_t)(int8_t)o_rew.b;
+            } else {
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    const uint32_t nz = __builtin_popcount(o_rew.w[q] & 0x01010101u), ng = __builtin_popcount(o_rew.w[q] & 0x80808080u);
+                    fin_tot += __builtin_popcount((o_term.w[q] | o_trunc.w[q]) & 0x01010101u);
+                    nonzero += nz; rew_tot += (int32_t)nz - 2 * (int32_t)ng;
+                }
+            }
+        }
+        const long long off = (long long)s * IO.out_stride;
+        if (IO.obs) o_obs.store(IO.obs + off, i0);
+        if (IO.reward) o_rew.store(IO.reward + off, i0);
+        if (IO.terminated) o_term.store(IO.terminated + off, i0);
+        if (IO.truncated) o_trunc.store(IO.truncated + off, i0);
+        aa = naa; ab = nab;
+    }
+}
+
+template <int E, bool DYN>
+__device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const uint32_t* isd, const TransTables& TT,
+                                                    const KernelParams& P, const RolloutIO& IO,
+                                                    unsigned long long i0, unsigned long long tick0,
+                                                    HistAcc<false>& hist, bool& any_misuse) {
+    const uint32_t nS = (uint32_t)TT.nS;
+    uint32_t c[E], t[E], need[E];
+    uint32_t frozen_mask = 0u;
+    bool special = P.autoreset == 0u;       // any lane frozen or in a goal tuple on entry, or no auto-reset
+    {
+        RawState<E> raw; raw.load(P, i0);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t f = (mad24(mad24(raw.ra.get(j), (uint32_t)P.W, raw.ca.get(j)), (uint32_t)P.HW,
+                                      mad24(raw.rb.get(j), (uint32_t)P.W, raw.cb.get(j))) << 1) | (raw.ps.get(j) & 1u);
+            const uint32_t code = TT.code_lut[f];
+            const bool bad = code >= (uint32_t)TT.n_codes;              // unreachable tuple written behind the API's back
+            c[j] = bad ? 0u : code; t[j] = raw.tt.get(j);
+            need[j] = bad ? 1u : ((raw.ps.get(j) >> 1) & 1u);
+            frozen_mask |= need[j] << j;
+            special |= (need[j] != 0u) | (c[j] >= nS);
+        }
+    }
+    int32_t acc[E];                         // per lane: return << 16 (signed) + finished episodes (a launch has <= 4096 steps)
+    uint32_t nonzero = 0u, fin_tot = 0u; int32_t rew_tot = 0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[j] = 0;
+    if (special) table_steps<E, DYN, true>(trans, isd, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
+    else table_steps<E, DYN, false>(trans, isd, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
+    {   // codes back to tuples; lanes that were frozen on entry keep their bytes (rare: re-read them)
+        PackB<E> ra, ca, rb, cb, ps, tt;
+        ra.clear(); ca.clear(); rb.clear(); cb.clear(); ps.clear(); tt.clear();
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t tup = TT.code_tuple[c[j]];
+            ra.put(j, tup & 15u); ca.put(j, (tup >> 4) & 15u); rb.put(j, (tup >> 8) & 15u); cb.put(j, (tup >> 12) & 15u);
+            ps.put(j, ((tup >> 16) & 1u) | (need[j] << 1)); tt.put(j, t[j]);
+        }
+        if (frozen_mask) {
+            RawState<E> raw; raw.load(P, i0);
+            if constexpr (E == 1) {
+                ra.b = raw.ra.b; ca.b = raw.ca.b; rb.b = raw.rb.b; cb.b = raw.cb.b; ps.b = raw.ps.b; tt.b = raw.tt.b;
+            } else {
+                static_assert(E == 1 || E == 4, "the table rollout packs 4 lanes per dword");
+                uint32_t m = 0u;                                        // byte mask of the frozen lanes
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m |= ((frozen_mask >> j) & 1u) ? (0xffu << (8 * j)) : 0u;
+                ra.w[0] = (ra.w[0] & ~m) | (raw.ra.w[0] & m); ca.w[0] = (ca.w[0] & ~m) | (raw.ca.w[0] & m);
+                rb.w[0] = (rb.w[0] & ~m) | (raw.rb.w[0] & m); cb.w[0] = (cb.w[0] & ~m) | (raw.cb.w[0] & m);
+                ps.w[0] = (ps.w[0] & ~m) | (raw.ps.w[0] & m); tt.w[0] = (tt.w[0] & ~m) | (raw.tt.w[0] & m);
+            }
+        }
+        uint8_t* sp = P.state;
+        ra.store(sp, i0); ca.store(sp + P.state_stride, i0); rb.store(sp + 2 * P.state_stride, i0);
+        cb.store(sp + 3 * P.state_stride, i0); ps.store(sp + 4 * P.state_stride, i0); tt.store(sp + 5 * P.state_stride, i0);
+    }
+    hist.add_totals(fin_tot, rew_tot, nonzero);
+    if (IO.return_sum || IO.episode_count) {
+        int32_t ret[E], eps[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) { eps[j] = acc[j] & 0xffff; ret[j] = (acc[j] - eps[j]) >> 16; }   // finished <= 4096 < 2^16
+        if (IO.return_sum) add_words<E>(IO.return_sum, i0, ret);
+        if (IO.episode_count) add_words<E>(IO.episode_count, i0, eps);
+    }
+}
+
+template <int E, bool DYN>
+__global__ __launch_bounds__(kTblBlock) void rollout_table_kernel(const KernelParams P, const RolloutIO IO, const TransTables TT) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    HistAcc<false> hist; hist.init(P);
+    if (threadIdx.x < kIsdWords) smem[threadIdx.x] = P.isd[threadIdx.x];
+    uint32_t* trans = smem + kIsdWords;
+    {
+        const int n4 = (TT.nS * 25) >> 2;                               // nS * 25 words, copied as dwordx4 + tail
+        const uint4* src = reinterpret_cast<const uint4*>(TT.trans);
+        uint4* dst = reinterpret_cast<uint4*>(trans);
+        for (int i = threadIdx.x; i < n4; i += kTblBlock) dst[i] = src[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < TT.nS * 25; i += kTblBlock) trans[i] = TT.trans[i];
+    }
+    __syncthreads();
+    const unsigned long long tick0 = *P.tick_in;
+    publish_tick(P, tick0, (unsigned long long)IO.n_steps);
+    const unsigned long long groups = (P.n + E - 1) / E;
+    bool any_misuse = false;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * kTblBlock + threadIdx.x; g < groups;
+         g += (unsigned long long)gridDim.x * kTblBlock) {
+        const unsigned long long i0 = g * E;
+        if (E == 1 || i0 + E <= P.n) {
+            rollout_table_group<E, DYN>(trans, smem, TT, P, IO, i0, tick0, hist, any_misuse);
+        } else {
+            for (unsigned long long i = i0; i < P.n; ++i)
+                rollout_table_group<1, DYN>(trans, smem, TT, P, IO, i, tick0, hist, any_misuse);
         }
     }
     if (any_misuse) *P.misuse = 1u;
