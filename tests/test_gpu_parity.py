@@ -451,6 +451,89 @@ def test_rollout_equals_successive_steps_and_sampled_actions_match_oracle():
         b.close()
 
 
+def _rollout_vs_oracle(b, o, acts_a, acts_b, policy=None, fixed=None):
+    """T fused steps against T oracle steps: every output of every lane and step, state, histogram."""
+    T, n = (acts_a if acts_a is not None else acts_b).shape
+    A = None if acts_a is None else b.alloc((T, n), np.int8).upload(acts_a)
+    B = None if acts_b is None else b.alloc((T, n), np.int8).upload(acts_b)
+    obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8)
+    term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
+    rs = b.alloc(n, np.int32).fill(0); ec = b.alloc(n, np.int32).fill(0)
+    hist0 = int(o.hist.sum())
+    cur = None
+    if fixed:                                   # the oracle side gathers the fixed side's action on the host
+        lut = o.tables()[0]
+        f = ((((o.row_a.astype(np.int64) * o.W + o.col_a) * o.H + o.row_b) * o.W + o.col_b) << 1) | (o.poss & 1)
+        cur = lut[f]
+    b.rollout(T, A, B, act_stride=n, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
+              return_sum=rs, episode_count=ec)
+    O, R, TE, TR = obs.download(), rew.download(), term.download(), trunc.download()
+    ret = np.zeros(n, np.int64)
+    for k in range(T):
+        a = policy[cur] if fixed == "player_a" else acts_a[k]
+        bb = policy[cur] if fixed == "player_b" else acts_b[k]
+        c = o.step(a, bb)
+        np.testing.assert_array_equal(O[k], c["obs"], err_msg="obs step %d" % k)
+        np.testing.assert_array_equal(R[k], c["reward"], err_msg="reward step %d" % k)
+        np.testing.assert_array_equal(TE[k], c["terminated"], err_msg="terminated step %d" % k)
+        np.testing.assert_array_equal(TR[k], c["truncated"], err_msg="truncated step %d" % k)
+        ret += c["reward"]
+        cur = c["obs"]
+    assert_state_equal(b, o)
+    np.testing.assert_array_equal(rs.download(), ret)
+    np.testing.assert_array_equal(b.stats()[0], o.hist)
+    assert int(ec.download().sum()) == int(o.hist.sum()) - hist0
+
+
+@pytest.mark.parametrize("width,height", [(5, 4), (6, 4), (7, 5)])
+def test_table_rollout_special_lanes_and_no_autoreset(width, height):
+    """batched_rollout at slip 0 runs through the LDS transition table when it fits (5x4, 6x4; 7x5 falls back
+    to the rule-function kernel): lanes frozen on entry, lanes injected into goal tuples, mixed with ordinary
+    lanes inside one thread's group of four; handles without auto-reset; a ragged lane count."""
+    rng = np.random.default_rng(21)
+    n, T = 4099, 130
+    ot = Oracle(width, height, 0.0, n=1)
+    lut, kind, *_ = ot.tables()
+    W = width + 2
+    def tuples(fl):
+        p_ = fl & 1; r = fl >> 1; yb = r % W; r //= W; xb = r % height; r //= height; ya = r % W; xa = r // W
+        return xa, ya, xb, yb, p_
+    live, goal = np.flatnonzero(kind == 1), np.flatnonzero(kind == 2)
+    for autoreset in (True, False):
+        b = SoccerBatch(n, width, height, 0.0, seed=31, autoreset=autoreset)
+        o = Oracle(width, height, 0.0, n=n, seed=31, autoreset=autoreset)
+        # a third of the lanes in goal tuples (needs_reset 0: absorbing step), a third frozen, the rest live
+        fl = np.where(rng.random(n) < 0.33, rng.choice(goal, n), rng.choice(live, n))
+        nr = (rng.random(n) < 0.33).astype(np.uint8)
+        t0 = rng.choice([0, 3, 97, 99, 100], n).astype(np.uint8)
+        xa, ya, xb, yb, p_ = tuples(fl)
+        for x in (b, o):
+            x.set_state(xa, ya, xb, yb, p_, t=t0, needs_reset=nr)
+        acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+        _rollout_vs_oracle(b, o, acts[:, 0], acts[:, 1])
+        assert b.stats()[1] == 1                         # frozen lanes were stepped: sticky misuse flag
+        b.reset_stats()
+        # and from a clean reset (auto-reset on: the steady-state loop; off: lanes freeze as they finish)
+        b.reset(); o.reset(); o.hist[:] = 0; b.reset_stats()
+        _rollout_vs_oracle(b, o, acts[:, 0], acts[:, 1])
+        assert b.stats()[1] == (0 if autoreset else 1)
+        b.close()
+
+
+@pytest.mark.parametrize("fixed", ["player_a", "player_b"])
+def test_table_rollout_single_agent_policy(fixed):
+    n, T = 2048, 110
+    rng = np.random.default_rng(4)
+    policy = rng.integers(0, 5, size=761).astype(np.int8)
+    acts = rng.integers(0, 5, size=(T, n), dtype=np.int8)
+    b = SoccerBatch(n, 5, 4, 0.0, seed=8, autoreset=True); b.set_policy(fixed, policy)
+    o = Oracle(5, 4, 0.0, n=n, seed=8, autoreset=True)
+    b.reset(); o.reset()
+    _rollout_vs_oracle(b, o, None if fixed == "player_a" else acts, None if fixed == "player_b" else acts,
+                       policy=policy, fixed=fixed)
+    b.close()
+
+
 def test_config5_selfplay_rollout_histogram_matches_cpu_exactly():
     """BASELINE config 5: 2^20 lanes x 100-step horizon, both players sampling from mixed policy tables
     in-kernel (per-lane Philox), reward histogram compared with the CPU oracle — exact counts, since
