@@ -391,6 +391,12 @@ class SoccerBatch:
         self._check(self.lib.soccer_get_stats(self.h, C.byref(hist), C.byref(mis)))
         return np.array(hist, dtype=np.uint64), int(mis.value)
 
+    def misuse(self):
+        """The sticky misuse flag alone (no histogram copy): nonzero if a lane was stepped while it needed reset."""
+        mis = C.c_uint64()
+        self._check(self.lib.soccer_get_stats(self.h, None, C.byref(mis)))
+        return int(mis.value)
+
     def reset_stats(self):
         self._check(self.lib.soccer_reset_stats(self.h))
 

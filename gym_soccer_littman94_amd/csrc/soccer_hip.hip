@@ -39,7 +39,9 @@ struct soccer_handle {
     int8_t* d_policy[2] = {nullptr, nullptr};
     unsigned long long* d_tick = nullptr;   // two slots, 128 B apart
     unsigned long long* d_hist = nullptr;
-    unsigned int* d_misuse = nullptr;
+    unsigned int* d_misuse = nullptr;       // device alias of misuse_host
+    unsigned int* misuse_host = nullptr;    // pinned + mapped: kernels store to it only when a frozen lane is stepped (rare),
+                                            // the host reads it without a copy
     uint8_t* d_state = nullptr;             // one allocation holding the six SoA streams back to back
     size_t state_stride = 0;                // bytes between consecutive streams
     uint8_t* stage_dev = nullptr;           // staging for the host-pointer entry points
@@ -102,12 +104,13 @@ static void free_handle(soccer_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->d_misuse, h->stage_dev,
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev,
                     h->d_trans, h->d_code_lut, h->d_code_tuple};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->rec_host) (void)hipHostFree(h->rec_host);
+    if (h->misuse_host) (void)hipHostFree(h->misuse_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -256,8 +259,9 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     CREATE_TRY(hipMemset(h->d_tick, 0, 256));
     CREATE_TRY(hipMalloc(&h->d_hist, sizeof(unsigned long long) * kHistSlots * kHistStride));
     CREATE_TRY(hipMemset(h->d_hist, 0, sizeof(unsigned long long) * kHistSlots * kHistStride));
-    CREATE_TRY(hipMalloc(&h->d_misuse, 128));
-    CREATE_TRY(hipMemset(h->d_misuse, 0, 128));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->misuse_host), 128, hipHostMallocMapped));
+    std::memset(h->misuse_host, 0, 128);
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_misuse), h->misuse_host, 0));
 
     P.next_cell = h->d_nc; P.isd = h->d_isd;
     P.hist = h->d_hist; P.misuse = h->d_misuse;
@@ -1100,11 +1104,7 @@ extern "C" int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* mi
         hist[0] = hist[1] = hist[2] = 0;
         for (int s = 0; s < kHistSlots; ++s) for (int b = 0; b < 3; ++b) hist[b] += shards[(size_t)s * kHistStride + b];
     }
-    if (misuse) {
-        unsigned int m = 0;
-        HIP_TRY(h, hipMemcpy(&m, h->d_misuse, sizeof m, hipMemcpyDeviceToHost));
-        *misuse = m;
-    }
+    if (misuse) *misuse = *static_cast<volatile unsigned int*>(h->misuse_host);   // the stream is idle: no copy needed
     return SOCCER_OK;
 }
 

@@ -149,7 +149,10 @@ class VectorSoccerEnv:
                     continue
                 x = np.asarray(x)
                 assert x.shape == (n,), "one action per environment and agent"
-                assert ((x >= 0) & (x < self.nA)).all(), "actions must be in 0..4"
+                if x.dtype == np.int8:                      # one reduction: negative values read as >= 128
+                    assert n == 0 or x.view(np.uint8).max() < self.nA, "actions must be in 0..4"
+                else:
+                    assert ((x >= 0) & (x < self.nA)).all(), "actions must be in 0..4"
                 np.copyto(stg[key], x, casting="unsafe")
             b.step_staged(act_a=a is not None, act_b=bb is not None)
             out = {k: stg[k].copy() for k in ("obs", "final_obs", "reward", "terminated", "truncated", "prob_code")} \
@@ -184,8 +187,7 @@ class VectorSoccerEnv:
                 {ag: term for ag in ags}, {ag: trunc for ag in ags}, infos)
 
     def _raise_on_misuse(self):
-        hist, misuse = self._batch.stats()
-        if misuse:
+        if self._batch.misuse():
             self._batch.reset_stats()
             raise AssertionError("Please reset the environment before taking a step "
                                  "(some lanes had terminated or truncated; they were left untouched)")

@@ -6,14 +6,15 @@ sys.path.insert(0, ".")
 import torch
 from gym_soccer_littman94_amd import VectorSoccerEnv
 
-for n in (1 << 16, 1 << 20):
+sizes = [int(x) for x in sys.argv[1:]] or [1 << 16, 1 << 20]
+for n in sizes:
     rng = np.random.default_rng(0)
     a = rng.integers(0, 5, size=(8, 2, n)).astype(np.int8)
     for copy in (True, False):
         v = VectorSoccerEnv(n, seed=0, copy=copy)
         v.reset()
         for k in range(3): v.step({'player_a': a[k, 0], 'player_b': a[k, 1]})
-        t = time.perf_counter(); K = 30
+        t = time.perf_counter(); K = 30 if n > 65536 else 2000
         for k in range(K): v.step({'player_a': a[k % 8, 0], 'player_b': a[k % 8, 1]})
         dt = time.perf_counter() - t
         print("numpy  io  n=%8d copy=%-5s: %8.1f us/step  %.3g env-steps/s" % (n, copy, dt / K * 1e6, n * K / dt))
