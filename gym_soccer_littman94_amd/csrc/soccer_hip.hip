@@ -61,6 +61,7 @@ struct soccer_handle {
     // LDS transition-table rollout (slip 0, table fits the LDS): see rollout_table_kernel
     uint32_t* d_trans = nullptr; uint16_t* d_code_lut = nullptr; uint32_t* d_code_tuple = nullptr;
     TransTables TT{}; bool table_ok = false; size_t table_smem = 0; int n_cu = 256;
+    uint4* d_sub = nullptr;                 // integer slip thresholds (KernelParams::sub)
     uint4* rec_host = nullptr; uint4* rec_dev = nullptr; uint32_t rec_seq = 0;   // soccer_step_scalar's mapped result record
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
@@ -105,7 +106,7 @@ static void free_handle(soccer_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
     void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev,
-                    h->d_trans, h->d_code_lut, h->d_code_tuple};
+                    h->d_trans, h->d_code_lut, h->d_code_tuple, h->d_sub};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -292,6 +293,37 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
             acc = acc + wc;
             P.B[P.nb] = acc; P.act_pack |= (unsigned long long)c << (4 * P.nb); ++P.nb;
         }
+    }
+    // Integer form of the slip decision for Philox draws u = m * 2^-30 (KernelParams::CB / sub): scaling by
+    // 2^30 is exact, so u >= b <=> m >= ceil(b * 2^30).  Allowed only if no scaled threshold lies within 2^-10
+    // of an integer (then no draw can be within 2^-40 of a threshold and the nominal decision is the exact
+    // one) and the last cumulative weight exceeds every possible draw.
+    {
+        static const int cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+        bool ok = cfg->slip_prob != 0.0 && P.nb >= 1;
+        auto scaled = [&](double t, uint32_t& out) {
+            const double x = t * 0x1.0p30;                              // exact
+            if (!(x >= 0.0) || x > 0x1.0p31) { ok = false; out = 0xFFFFFFFFu; return; }
+            const double r = __builtin_nearbyint(x);
+            if (__builtin_fabs(x - r) < 0x1.0p-10 && r < 0x1.0p30) ok = false;   // a draw m = r (< 2^30) could sit on / next to it
+            out = (uint32_t)__builtin_ceil(x);
+        };
+        std::vector<uint4> sub(9, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
+        for (int i = 0; i < 9; ++i) P.CB[i] = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < P.nb && i < 9; ++i) {
+            scaled(P.B[i], P.CB[i]);
+            const int c = (int)((P.act_pack >> (4 * i)) & 0xf);
+            volatile double S = i ? P.B[i - 1] : 0.0;
+            volatile double q2 = P.w[cls[c]] * 0.5, q4 = P.w[cls[c]] * 0.25;
+            volatile double a1 = S + q2;                                 // two outcomes: t1
+            volatile double b1 = S + q4; volatile double b2 = b1 + q4; volatile double b3 = b2 + q4;   // four: t1, t2, t3
+            scaled(a1, sub[i].x); scaled(b1, sub[i].y); scaled(b2, sub[i].z); scaled(b3, sub[i].w);
+        }
+        if (ok && P.CB[P.nb - 1] < (1u << 30)) ok = false;             // some draw would fall beyond the last entry
+        P.slip_int = ok ? 1u : 0u;
+        CREATE_TRY(hipMalloc(&h->d_sub, sub.size() * sizeof(uint4)));
+        CREATE_TRY(hipMemcpy(h->d_sub, sub.data(), sub.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        P.sub = h->d_sub;
     }
     set_key(h, cfg->seed);
     h->slip = cfg->slip_prob != 0.0;

@@ -63,6 +63,13 @@ struct KernelParams {
     // slip fast path: cumulative weight after each ACTIVE (non-zero) combination in reference order
     // (+inf beyond), their count, and their combination ids packed 4 bits each
     double B[9]; uint32_t nb; unsigned long long act_pack;
+    // integer form of the same decision for draws that come from a Philox word (u = m * 2^-30, m < 2^30):
+    // u >= b  <=>  m >= ceil(b * 2^30).  Used only when the host has checked that NO threshold of the handle
+    // (9 combination ends CB, 9 x 4 within-combination thresholds `sub`) lies within 2^-10 of an integer after
+    // scaling, i.e. that no such draw can be within 2^-40 of a threshold: then the nominal decision is the exact one
+    // and the float64 walk is never needed (slip_int = 1).
+    uint32_t CB[9]; uint32_t slip_int;
+    const uint4* sub;                     // [9] per active combination: { t1 (2 outcomes), t1, t2, t3 (4 outcomes) }, scaled
 };
 
 struct StepIO {
@@ -113,11 +120,11 @@ __device__ __forceinline__ Philox4 lane_block(const KernelParams& P, unsigned lo
 
 // One lane's randomness for a step: the uniform as float64 (slip lists), floor(4u) (lists whose
 // probabilities are dyadic: slip_prob == 0) and two independent bits for the ISD draw.
-struct Draw { double u; uint32_t top2; uint32_t reset2; };
+struct Draw { double u; uint32_t top2; uint32_t reset2; uint32_t m; };   // m = w >> 2 for word draws
 
 // lane word w: u = (w >> 2) * 2^-30, reset bits = w & 3
 __device__ __forceinline__ Draw draw_from_word(uint32_t w) {
-    return Draw{(double)(w >> 2) * 0x1.0p-30, w >> 30, w & 3u};
+    return Draw{(double)(w >> 2) * 0x1.0p-30, w >> 30, w & 3u, w >> 2};
 }
 // A caller-supplied uniform.  Values outside [0,1) (and NaN) make every running sum compare
 // "not greater", which categorical_sample resolves to index 0 — same as u = 0.
@@ -239,7 +246,8 @@ __device__ __forceinline__ Outcome pick(uint32_t A, uint32_t B, uint32_t p, cons
 }
 
 // Returns true when the lane was stepped while it needed a reset (left untouched; :376).
-template <bool SLIP>
+// WORD: the draw is known to come from a Philox word (d.m valid), which allows the integer slip decision.
+template <bool SLIP, bool WORD = false>
 __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P, Lane& Lref,
                                           uint32_t aa, uint32_t ab, const Draw& d, StepResult& out) {
     const uint32_t A = Lref.A, B = Lref.B, p = Lref.p, t = Lref.t;
@@ -271,6 +279,25 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
             cellA[v] = moved(T, P, A, p ^ 1u, slip_move(aa, v));
             cellB[v] = moved(T, P, B, p, slip_move(ab, v));
         }
+        if (WORD && P.slip_int) {                                       // uniform
+            // Integer decision (see KernelParams::CB): combination = number of scaled cumulative weights <= m,
+            // outcome within it = number of its scaled thresholds <= m.  No float64, no fallback.
+            uint32_t idx = 0u;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) idx += d.m >= P.CB[i] ? 1u : 0u;
+            const uint32_t c_i = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull);
+            const uint32_t va = (VA2 >> (2u * c_i)) & 3u, vb = (VB2 >> (2u * c_i)) & 3u;
+            cls = (CL2 >> (2u * c_i)) & 3u;
+            const uint32_t cA = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
+            const uint32_t cB = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
+            Resolved R = classify(A, B, cA, cB, aa, ab);
+            R.kind = in_goal ? (uint32_t)K_MOVE : R.kind;
+            const uint4 th = P.sub[idx];
+            const bool two = R.kind == K_COIN, four = R.kind == K_FOUR;
+            const uint32_t k = (((two & (d.m >= th.x)) | (four & (d.m >= th.y))) ? 1u : 0u) +
+                               ((four & (d.m >= th.z)) ? 1u : 0u) + ((four & (d.m >= th.w)) ? 1u : 0u);
+            sel = pick(A, B, p, R, k);
+        } else {
         // (1) Fast decision.  The list's running sums are, up to rounding, the cumulative weights of the
         // active combinations (P.B, summed on the host in the reference's order) plus multiples of the
         // combination's own q; the true float64 sums differ from these nominal values by < 1e-14 (at most
@@ -341,6 +368,7 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         const uint32_t sA_ = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
         const uint32_t sB_ = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
         sel = pick(A, B, p, classify(A, B, sA_, sB_, aa, ab), sel_k);
+        }
     }
     sel.A = in_goal ? A : sel.A; sel.B = in_goal ? B : sel.B; sel.p = in_goal ? p : sel.p;
     sel.kcode = in_goal ? 0u : sel.kcode;
@@ -667,7 +695,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
                 if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
             }
             StepResult R;
-            mis |= lane_step<SLIP>(T, P, L, a_now, b_now, d, R);
+            mis |= lane_step<SLIP, !EXPLICIT_U>(T, P, L, a_now, b_now, d, R);
             nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
             nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
             nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
@@ -738,7 +766,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
         L.B = make_pos(__builtin_amdgcn_ubfe(rb, sh, 8u), __builtin_amdgcn_ubfe(cb, sh, 8u), P.W);
         L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
         StepResult R;
-        mis |= lane_step<SLIP>(T, P, L, __builtin_amdgcn_ubfe(aa, sh, 8u), __builtin_amdgcn_ubfe(ab, sh, 8u),
+        mis |= lane_step<SLIP, true>(T, P, L, __builtin_amdgcn_ubfe(aa, sh, 8u), __builtin_amdgcn_ubfe(ab, sh, 8u),
                                draw_from_word(w), R);
         nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
         nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
@@ -834,7 +862,7 @@ __global__ __launch_bounds__(64) void scalar_kernel(const KernelParams P, const 
             if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
         }
         const double u = sane_uniform(IO.u_step);
-        const Draw d{u, (uint32_t)(u * 4.0), (uint32_t)(sane_uniform(IO.u_reset) * 4.0)};
+        const Draw d{u, (uint32_t)(u * 4.0), (uint32_t)(sane_uniform(IO.u_reset) * 4.0), 0u};
         (void)lane_step<SLIP>(T, P, L, a_now, b_now, d, R);
     }
     uint8_t* sw = P.state;
@@ -907,7 +935,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
                 if (P.policy_b) b = (uint32_t)(uint8_t)P.policy_b[s_now[j]];
             }
             StepResult R;
-            any_misuse |= lane_step<SLIP>(T, P, S.L[j], a, b, d, R);
+            any_misuse |= lane_step<SLIP, true>(T, P, S.L[j], a, b, d, R);
             if (DYN) s_now[j] = R.obs;
             o_obs.put(j, R.obs); o_rew.put(j, (uint32_t)R.reward & 0xffu); o_term.put(j, R.term); o_trunc.put(j, R.trunc);
             ret[j] += R.reward; eps[j] += (int32_t)R.finished; nonzero += (uint32_t)R.reward & 1u;

@@ -362,7 +362,10 @@ def test_single_agent_rollout_and_step_agree_with_oracle_policy_gather():
     b.close(); b2.close()
 
 
-@pytest.mark.parametrize("slip,n,off", [(0.0, 65536, 0), (0.0, 65536 + 6, 1 << 33), (0.2, 32768, 4 * 123457), (0.0, 5, 0), (0.2, 3, 8)])
+# slips 0.2 / 0.3 / 0.05 take the integer threshold decision (KernelParams::CB), 0.5 / 0.1 / 0.9 have a scaled
+# threshold on or next to an integer and stay on the float64 two-tier decision
+@pytest.mark.parametrize("slip,n,off", [(0.0, 65536, 0), (0.0, 65536 + 6, 1 << 33), (0.2, 32768, 4 * 123457), (0.0, 5, 0), (0.2, 3, 8),
+                                        (0.3, 16384, 0), (0.05, 16384, 8), (0.5, 16384, 0), (0.1, 8192, 0), (0.9, 8192, 4)])
 def test_hot_instantiation_plain_step_vs_oracle(slip, n, off):
     """The instantiation bench.py times: lane offset a multiple of 4 (one Philox block per thread), dword
     I/O, only the four mandatory outputs (LEAN), no step statistics — every lane, every step."""
@@ -418,7 +421,7 @@ def test_rollout_equals_successive_steps_and_sampled_actions_match_oracle():
     n, T = 32768 + 5, 64
     rng = np.random.default_rng(11)
     acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
-    for slip in (0.0, 0.2):
+    for slip in (0.0, 0.2, 0.3, 0.5):
         b = SoccerBatch(n, 5, 4, slip, seed=99, autoreset=True)
         o = Oracle(5, 4, slip, n=n, seed=99, autoreset=True)
         b.reset(); o.reset()
