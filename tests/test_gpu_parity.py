@@ -308,6 +308,80 @@ def test_host_mapped_handle_matches_a_device_resident_one():
     bm.close(); bd.close()
 
 
+def _outcomes_per_combination(o_tab, st, aa, ab, slip):
+    """Number of collision outcomes (1, 2 or 4; 0 = inactive) of each of the 9 slip combinations of a
+    transition list, recovered from the list's probabilities (weight * 1, .5 or .25 per entry)."""
+    s = np.float64(slip); om = np.float64(1) - s
+    w = [om * om, (om * s) * 0.5, (s * om) * 0.5, (s * s) * 0.25]
+    cls = [0, 1, 1, 2, 2, 3, 3, 3, 3]
+    probs = o_tab.transitions(st, aa, ab)[0]
+    out, i = [], 0
+    for c in range(9):
+        wc = w[cls[c]]
+        if wc == 0:
+            out.append(0); continue
+        n = 1 if probs[i] == wc else (2 if probs[i] == wc * 0.5 else 4)
+        assert probs[i] == wc * (1.0, 0.5, None, 0.25)[n - 1]
+        out.append(n); i += n
+    assert i == len(probs)
+    return out
+
+
+def test_philox_draws_on_slip_thresholds_match_the_float64_cumsum():
+    """The slip kernels decide u >= threshold on integers for Philox draws (u = m * 2^-30).  Replay draws whose
+    m sits exactly ON a scaled threshold or one below it (found by tools/find_threshold_draws.py in the handle's
+    own Philox stream) from states where that threshold separates two outcomes; the oracle walks the float64
+    running sum like categorical_sample.  Both the step and the rollout kernels."""
+    import json
+    d = json.load(open(os.path.join(GOLDEN, "threshold_draws.json")))
+    seed = d["seed"]
+    rng = np.random.default_rng(6)
+    tabs, checked, kinds = {}, 0, set()
+    for h in d["hits"]:
+        slip, g, tick = h["slip"], h["lane"], h["tick"]
+        if slip not in tabs:
+            ot = Oracle(5, 4, slip, n=1); lut, kind, *_ = ot.tables()
+            tabs[slip] = (ot, np.flatnonzero(kind == 1))
+        ot, live = tabs[slip]
+        lo, j = g & ~3, g & 3
+        b = SoccerBatch(4, 5, 4, slip, seed=seed, lane_offset=lo)
+        o = Oracle(5, 4, slip, n=4, seed=seed, lane_offset=lo)
+        for name, c in h["thresholds"]:
+            want_n = {"end": None, "two": 2}.get(name, 4)
+            trials = attempts = 0
+            while trials < 6:
+                attempts += 1
+                assert attempts < 20000, "no state found where combination %d has %s outcomes" % (c, want_n)
+                fl = rng.choice(live, 4)
+                p_ = fl & 1; r = fl >> 1; yb = r % 7; r //= 7; xb = r % 4; r //= 4; ya = r % 7; xa = r // 7
+                a = rng.integers(0, 5, 4).astype(np.int8); bb = rng.integers(0, 5, 4).astype(np.int8)
+                if want_n is not None:
+                    n_c = _outcomes_per_combination(ot, (xa[j], ya[j], xb[j], yb[j], p_[j]), int(a[j]), int(bb[j]), slip)
+                    if n_c[c] != want_n:
+                        continue
+                trials += 1
+                for mode in ("step", "rollout"):
+                    for x in (b, o):
+                        x.set_state(xa, ya, xb, yb, p_, t=0, needs_reset=np.zeros(4, np.uint8))
+                    b._check(b.lib.soccer_set_tick(b.h, tick)); o.tick = tick
+                    # the lane's word really is the recorded draw
+                    if mode == "step":
+                        got = b.step_host(a, bb)
+                    else:
+                        A = b.alloc(4, np.int8).upload(a); B = b.alloc(4, np.int8).upload(bb)
+                        ob = b.alloc(4, np.uint16); rw = b.alloc(4, np.int8); te = b.alloc(4, np.uint8); tr = b.alloc(4, np.uint8)
+                        b.rollout(1, A, B, act_stride=4, obs=ob, reward=rw, terminated=te, truncated=tr, out_stride=4)
+                        got = {"obs": ob.download(), "reward": rw.download(), "terminated": te.download(), "truncated": tr.download()}
+                    want = o.step(a, bb)
+                    for k in ("obs", "reward", "terminated", "truncated"):
+                        np.testing.assert_array_equal(got[k], want[k], err_msg="%s %s %r" % (mode, k, h))
+                    assert_state_equal(b, o)
+                    checked += 1
+            kinds.add(name)
+        b.close()
+    assert checked > 300 and kinds == {"end", "two", "four1", "four2", "four3"}
+
+
 @pytest.mark.parametrize("learner", ["player_a", "player_b"])
 def test_single_agent_tables_every_row(learner):
     """Fixed-opponent mode against the REFERENCE's single-agent transition table (all ~43 000 rows):
