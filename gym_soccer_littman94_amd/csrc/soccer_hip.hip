@@ -358,11 +358,11 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
     h->grid_cap = prop.multiProcessorCount * 8;
     h->n_cu = prop.multiProcessorCount;
-    if (!h->slip) {     // LDS transition table for batched_rollout, when it fits
+    if (!h->slip || P.slip_int) {     // LDS transition table for batched_rollout, when it fits (slip: integer decision only)
         std::vector<uint32_t> trans, code_tuple; std::vector<uint16_t> code_lut; bool fits = false;
         const std::string terr = build_transition_table(R, trans, code_lut, code_tuple, fits);
         if (!terr.empty()) { free_handle(h); return fail(nullptr, SOCCER_E_INVALID, "%s", terr.c_str()); }
-        const size_t smem = (trans.size() + kIsdWords) * sizeof(uint32_t);
+        const size_t smem = (trans.size() + kTblHead) * sizeof(uint32_t);
         if (fits && smem <= 150 * 1024) {
             CREATE_TRY(hipMalloc(&h->d_trans, trans.size() * 4 + 16));
             CREATE_TRY(hipMemcpy(h->d_trans, trans.data(), trans.size() * 4, hipMemcpyHostToDevice));
@@ -373,7 +373,9 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
             h->TT = TransTables{h->d_trans, h->d_code_lut, h->d_code_tuple, R.nS, (int32_t)code_tuple.size()};
             h->table_smem = smem;
             hipError_t se = hipSuccess;
-#define RAISE_T(EV, DV) if (se == hipSuccess) se = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_table_kernel<EV, DV>), \
+#define RAISE_T(EV, DV) if (se == hipSuccess) se = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_table_kernel<EV, DV, false>), \
+                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+                        if (se == hipSuccess) se = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_table_kernel<EV, DV, true>), \
                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             RAISE_T(1, false) RAISE_T(1, true) RAISE_T(4, false) RAISE_T(4, true)
 #undef RAISE_T
@@ -584,10 +586,12 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             uint64_t blocks = (groups + kTblBlock - 1) / kTblBlock;
             if (blocks > (uint64_t)h->n_cu) blocks = h->n_cu;
             const dim3 g((unsigned)blocks), bl(kTblBlock);
-            if (ET == 4) { if (dyn) hipLaunchKernelGGL((rollout_table_kernel<4, true>), g, bl, h->table_smem, h->stream, P, io, h->TT);
-                           else hipLaunchKernelGGL((rollout_table_kernel<4, false>), g, bl, h->table_smem, h->stream, P, io, h->TT); }
-            else { if (dyn) hipLaunchKernelGGL((rollout_table_kernel<1, true>), g, bl, h->table_smem, h->stream, P, io, h->TT);
-                   else hipLaunchKernelGGL((rollout_table_kernel<1, false>), g, bl, h->table_smem, h->stream, P, io, h->TT); }
+#define LAUNCH_T(EV, DV, SV) hipLaunchKernelGGL((rollout_table_kernel<EV, DV, SV>), g, bl, h->table_smem, h->stream, P, io, h->TT)
+            if (h->slip) { if (ET == 4) { if (dyn) LAUNCH_T(4, true, true); else LAUNCH_T(4, false, true); }
+                           else { if (dyn) LAUNCH_T(1, true, true); else LAUNCH_T(1, false, true); } }
+            else { if (ET == 4) { if (dyn) LAUNCH_T(4, true, false); else LAUNCH_T(4, false, false); }
+                   else { if (dyn) LAUNCH_T(1, true, false); else LAUNCH_T(1, false, false); } }
+#undef LAUNCH_T
         } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;
             case 4: launch_rollout<4>(h, P, io); break;

@@ -1007,8 +1007,12 @@ constexpr int kTblBlock = 1024;          // one workgroup per CU shares one copy
 // lane is frozen or sits in a goal tuple on entry, so none ever will, and the code for those cases (and the
 // per-lane return / episode accumulators, unless asked for) is compiled out; episode totals come from
 // population counts over the packed output dwords.
-template <int E, bool DYN, bool GENERAL>
-__device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_t* isd, uint32_t nS,
+// SLIP (handles with slip_int only): the draw first selects one of the nine slip combinations by counting the
+// scaled cumulative weights <= m, the table is read at the SLIPPED joint action (a slipped move is NOOP exactly
+// when the original action is, so the entry's NOOP tests are the reference's), and the outcome within the
+// combination by counting its scaled thresholds <= m (KernelParams::CB / sub, here `sub` in LDS).
+template <int E, bool DYN, bool GENERAL, bool SLIP>
+__device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_t* isd, const uint4* sub, uint32_t nS,
                                             const KernelParams& P, const RolloutIO& IO,
                                             unsigned long long i0, unsigned long long tick0,
                                             uint32_t (&c)[E], uint32_t (&t)[E], uint32_t (&need)[E], int32_t (&acc)[E],
@@ -1056,9 +1060,31 @@ __device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_
                 if (P.policy_a) a = (uint32_t)(uint8_t)P.policy_a[s_now];
                 if (P.policy_b) b = (uint32_t)(uint8_t)P.policy_b[s_now];
             }
-            const uint32_t e = trans[mad24(s_now, 25u, mad24(a, 5u, b))];
-            const uint32_t kind = (e >> 28) & 3u;
-            const uint32_t k = kind == K_COIN ? (top2 >> 1) : top2;     // floor(2u) / floor(4u), as lane_step
+            uint32_t e, kind, k;
+            if (SLIP) {
+                const uint32_t m = words[j] >> 2;
+                uint32_t idx = 0u;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) idx += m >= P.CB[i] ? 1u : 0u;
+                const uint32_t c_i = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull);
+                constexpr uint32_t VA2 = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
+                constexpr uint32_t VB2 = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
+                const uint32_t va = (VA2 >> (2u * c_i)) & 3u, vb = (VB2 >> (2u * c_i)) & 3u;
+                // slip_move: NOOP->NOOP,NOOP  NORTH->EAST,WEST  SOUTH->WEST,EAST  EAST->SOUTH,NORTH  WEST->NORTH,SOUTH
+                const uint32_t a1 = (0x12430u >> (4u * a)) & 7u, a2 = (0x21340u >> (4u * a)) & 7u;
+                const uint32_t b1 = (0x12430u >> (4u * b)) & 7u, b2 = (0x21340u >> (4u * b)) & 7u;
+                const uint32_t as = va == 0u ? a : (va == 1u ? a1 : a2), bs = vb == 0u ? b : (vb == 1u ? b1 : b2);
+                e = trans[mad24(s_now, 25u, mad24(as, 5u, bs))];
+                kind = (e >> 28) & 3u;
+                const uint4 th = sub[idx];
+                const bool two = kind == K_COIN, four = kind == K_FOUR;
+                k = (((two & (m >= th.x)) | (four & (m >= th.y))) ? 1u : 0u) + ((four & (m >= th.z)) ? 1u : 0u) +
+                    ((four & (m >= th.w)) ? 1u : 0u);
+            } else {
+                e = trans[mad24(s_now, 25u, mad24(a, 5u, b))];
+                kind = (e >> 28) & 3u;
+                k = kind == K_COIN ? (top2 >> 1) : top2;                // floor(2u) / floor(4u), as lane_step
+            }
             const bool second = (kind == K_FOUR) & (k >= 2u);
             const uint32_t base = second ? ((e >> 14) & 0x3fffu) : (e & 0x3fffu);
             uint32_t nc = base + (kind >= K_COIN ? (k & 1u) : 0u);
@@ -1114,8 +1140,8 @@ __device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_
     }
 }
 
-template <int E, bool DYN>
-__device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const uint32_t* isd, const TransTables& TT,
+template <int E, bool DYN, bool SLIP>
+__device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const uint32_t* isd, const uint4* sub, const TransTables& TT,
                                                     const KernelParams& P, const RolloutIO& IO,
                                                     unsigned long long i0, unsigned long long tick0,
                                                     HistAcc<false>& hist, bool& any_misuse) {
@@ -1141,8 +1167,8 @@ __device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const
     uint32_t nonzero = 0u, fin_tot = 0u; int32_t rew_tot = 0;
 #pragma unroll
     for (int j = 0; j < E; ++j) acc[j] = 0;
-    if (special) table_steps<E, DYN, true>(trans, isd, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
-    else table_steps<E, DYN, false>(trans, isd, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
+    if (special) table_steps<E, DYN, true, SLIP>(trans, isd, sub, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
+    else table_steps<E, DYN, false, SLIP>(trans, isd, sub, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
     {   // codes back to tuples; lanes that were frozen on entry keep their bytes (rare: re-read them)
         PackB<E> ra, ca, rb, cb, ps, tt;
         ra.clear(); ca.clear(); rb.clear(); cb.clear(); ps.clear(); tt.clear();
@@ -1180,12 +1206,15 @@ __device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const
     }
 }
 
-template <int E, bool DYN>
+constexpr int kTblHead = kIsdWords + 36;     // LDS words ahead of the table: ISD entries, then the 9 x 4 slip thresholds
+
+template <int E, bool DYN, bool SLIP>
 __global__ __launch_bounds__(kTblBlock) void rollout_table_kernel(const KernelParams P, const RolloutIO IO, const TransTables TT) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     HistAcc<false> hist; hist.init(P);
     if (threadIdx.x < kIsdWords) smem[threadIdx.x] = P.isd[threadIdx.x];
-    uint32_t* trans = smem + kIsdWords;
+    if (SLIP && threadIdx.x < 36) smem[kIsdWords + threadIdx.x] = reinterpret_cast<const uint32_t*>(P.sub)[threadIdx.x];
+    uint32_t* trans = smem + kTblHead;
     {
         const int n4 = (TT.nS * 25) >> 2;                               // nS * 25 words, copied as dwordx4 + tail
         const uint4* src = reinterpret_cast<const uint4*>(TT.trans);
@@ -1194,6 +1223,7 @@ __global__ __launch_bounds__(kTblBlock) void rollout_table_kernel(const KernelPa
         for (int i = (n4 << 2) + threadIdx.x; i < TT.nS * 25; i += kTblBlock) trans[i] = TT.trans[i];
     }
     __syncthreads();
+    const uint4* sub = reinterpret_cast<const uint4*>(smem + kIsdWords);
     const unsigned long long tick0 = *P.tick_in;
     publish_tick(P, tick0, (unsigned long long)IO.n_steps);
     const unsigned long long groups = (P.n + E - 1) / E;
@@ -1202,10 +1232,10 @@ __global__ __launch_bounds__(kTblBlock) void rollout_table_kernel(const KernelPa
          g += (unsigned long long)gridDim.x * kTblBlock) {
         const unsigned long long i0 = g * E;
         if (E == 1 || i0 + E <= P.n) {
-            rollout_table_group<E, DYN>(trans, smem, TT, P, IO, i0, tick0, hist, any_misuse);
+            rollout_table_group<E, DYN, SLIP>(trans, smem, sub, TT, P, IO, i0, tick0, hist, any_misuse);
         } else {
             for (unsigned long long i = i0; i < P.n; ++i)
-                rollout_table_group<1, DYN>(trans, smem, TT, P, IO, i, tick0, hist, any_misuse);
+                rollout_table_group<1, DYN, SLIP>(trans, smem, sub, TT, P, IO, i, tick0, hist, any_misuse);
         }
     }
     if (any_misuse) *P.misuse = 1u;

@@ -562,14 +562,15 @@ def _rollout_vs_oracle(b, o, acts_a, acts_b, policy=None, fixed=None):
     assert int(ec.download().sum()) == int(o.hist.sum()) - hist0
 
 
-@pytest.mark.parametrize("width,height", [(5, 4), (6, 4), (7, 5)])
-def test_table_rollout_special_lanes_and_no_autoreset(width, height):
-    """batched_rollout at slip 0 runs through the LDS transition table when it fits (5x4, 6x4; 7x5 falls back
-    to the rule-function kernel): lanes frozen on entry, lanes injected into goal tuples, mixed with ordinary
-    lanes inside one thread's group of four; handles without auto-reset; a ragged lane count."""
+@pytest.mark.parametrize("width,height,slip", [(5, 4, 0.0), (6, 4, 0.0), (7, 5, 0.0), (5, 4, 0.2), (6, 4, 0.3), (5, 4, 0.5)])
+def test_table_rollout_special_lanes_and_no_autoreset(width, height, slip):
+    """batched_rollout runs through the LDS transition table when it fits (5x4, 6x4; 7x5 falls back to the
+    rule-function kernel) and, with slip, when the handle qualifies for the integer decision (0.2, 0.3; 0.5
+    falls back): lanes frozen on entry, lanes injected into goal tuples, mixed with ordinary lanes inside one
+    thread's group of four; handles without auto-reset; a ragged lane count."""
     rng = np.random.default_rng(21)
     n, T = 4099, 130
-    ot = Oracle(width, height, 0.0, n=1)
+    ot = Oracle(width, height, slip, n=1)
     lut, kind, *_ = ot.tables()
     W = width + 2
     def tuples(fl):
@@ -577,8 +578,8 @@ def test_table_rollout_special_lanes_and_no_autoreset(width, height):
         return xa, ya, xb, yb, p_
     live, goal = np.flatnonzero(kind == 1), np.flatnonzero(kind == 2)
     for autoreset in (True, False):
-        b = SoccerBatch(n, width, height, 0.0, seed=31, autoreset=autoreset)
-        o = Oracle(width, height, 0.0, n=n, seed=31, autoreset=autoreset)
+        b = SoccerBatch(n, width, height, slip, seed=31, autoreset=autoreset)
+        o = Oracle(width, height, slip, n=n, seed=31, autoreset=autoreset)
         # a third of the lanes in goal tuples (needs_reset 0: absorbing step), a third frozen, the rest live
         fl = np.where(rng.random(n) < 0.33, rng.choice(goal, n), rng.choice(live, n))
         nr = (rng.random(n) < 0.33).astype(np.uint8)
