@@ -247,7 +247,8 @@ __device__ __forceinline__ Outcome pick(uint32_t A, uint32_t B, uint32_t p, cons
 
 // Returns true when the lane was stepped while it needed a reset (left untouched; :376).
 // WORD: the draw is known to come from a Philox word (d.m valid), which allows the integer slip decision.
-template <bool SLIP, bool WORD = false>
+// INT_ONLY: the caller has checked P.slip_int on the host; the float64 decision is compiled out.
+template <bool SLIP, bool WORD = false, bool INT_ONLY = false>
 __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P, Lane& Lref,
                                           uint32_t aa, uint32_t ab, const Draw& d, StepResult& out) {
     const uint32_t A = Lref.A, B = Lref.B, p = Lref.p, t = Lref.t;
@@ -271,6 +272,27 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         constexpr uint32_t CL2 = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
         const double w0 = P.w[0], w1 = P.w[1], w2 = P.w[2], w3 = P.w[3];
 #define SOCCER_WEIGHT_OF(cl) (((cl) & 2u) ? (((cl) & 1u) ? w3 : w2) : (((cl) & 1u) ? w1 : w0))
+        if (INT_ONLY || (WORD && P.slip_int)) {                         // uniform
+            // Integer decision (see KernelParams::CB): combination = number of scaled cumulative weights <= m,
+            // outcome within it = number of its scaled thresholds <= m.  No float64, no fallback — and the
+            // combination is known before the move table is read, so two reads suffice.
+            uint32_t idx = 0u;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) idx += d.m >= P.CB[i] ? 1u : 0u;
+            const uint32_t c_i = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull);
+            const uint32_t va = (VA2 >> (2u * c_i)) & 3u, vb = (VB2 >> (2u * c_i)) & 3u;
+            cls = (CL2 >> (2u * c_i)) & 3u;
+            const uint32_t as = va == 0u ? aa : (((va == 1u ? 0x12430u : 0x21340u) >> (4u * aa)) & 7u);   // slip_move
+            const uint32_t bs = vb == 0u ? ab : (((vb == 1u ? 0x12430u : 0x21340u) >> (4u * ab)) & 7u);
+            const uint32_t cA = moved(T, P, A, p ^ 1u, as), cB = moved(T, P, B, p, bs);
+            Resolved R = classify(A, B, cA, cB, aa, ab);
+            R.kind = in_goal ? (uint32_t)K_MOVE : R.kind;
+            const uint4 th = P.sub[idx];
+            const bool two = R.kind == K_COIN, four = R.kind == K_FOUR;
+            const uint32_t k = (((two & (d.m >= th.x)) | (four & (d.m >= th.y))) ? 1u : 0u) +
+                               ((four & (d.m >= th.z)) ? 1u : 0u) + ((four & (d.m >= th.w)) ? 1u : 0u);
+            sel = pick(A, B, p, R, k);
+        } else if constexpr (!INT_ONLY) {
         // each player has only three distinct moves (intended + two orthogonals): 6 table reads serve
         // all nine combinations
         uint32_t cellA[3], cellB[3];
@@ -279,25 +301,6 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
             cellA[v] = moved(T, P, A, p ^ 1u, slip_move(aa, v));
             cellB[v] = moved(T, P, B, p, slip_move(ab, v));
         }
-        if (WORD && P.slip_int) {                                       // uniform
-            // Integer decision (see KernelParams::CB): combination = number of scaled cumulative weights <= m,
-            // outcome within it = number of its scaled thresholds <= m.  No float64, no fallback.
-            uint32_t idx = 0u;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) idx += d.m >= P.CB[i] ? 1u : 0u;
-            const uint32_t c_i = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull);
-            const uint32_t va = (VA2 >> (2u * c_i)) & 3u, vb = (VB2 >> (2u * c_i)) & 3u;
-            cls = (CL2 >> (2u * c_i)) & 3u;
-            const uint32_t cA = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
-            const uint32_t cB = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
-            Resolved R = classify(A, B, cA, cB, aa, ab);
-            R.kind = in_goal ? (uint32_t)K_MOVE : R.kind;
-            const uint4 th = P.sub[idx];
-            const bool two = R.kind == K_COIN, four = R.kind == K_FOUR;
-            const uint32_t k = (((two & (d.m >= th.x)) | (four & (d.m >= th.y))) ? 1u : 0u) +
-                               ((four & (d.m >= th.z)) ? 1u : 0u) + ((four & (d.m >= th.w)) ? 1u : 0u);
-            sel = pick(A, B, p, R, k);
-        } else {
         // (1) Fast decision.  The list's running sums are, up to rounding, the cumulative weights of the
         // active combinations (P.B, summed on the host in the reference's order) plus multiples of the
         // combination's own q; the true float64 sums differ from these nominal values by < 1e-14 (at most
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
 // one group of 4 lanes per thread, no grid-stride loop, no fallback or optional-output code at all.
 // Same lane loop as step_kernel; kept separate because a launch starts with a cold instruction cache
 // and every instruction that is not fetched counts (-0.4 us per launch against step_kernel<..., LEAN>).
-template <bool SLIP>
+template <bool SLIP, bool INT_ONLY = false>
 __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& IO, unsigned long long g, unsigned long long tick) {
     const unsigned long long i0 = P.first + (g << 2);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
@@ -766,7 +769,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
         L.B = make_pos(__builtin_amdgcn_ubfe(rb, sh, 8u), __builtin_amdgcn_ubfe(cb, sh, 8u), P.W);
         L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
         StepResult R;
-        mis |= lane_step<SLIP, true>(T, P, L, __builtin_amdgcn_ubfe(aa, sh, 8u), __builtin_amdgcn_ubfe(ab, sh, 8u),
+        mis |= lane_step<SLIP, true, INT_ONLY>(T, P, L, __builtin_amdgcn_ubfe(aa, sh, 8u), __builtin_amdgcn_ubfe(ab, sh, 8u),
                                draw_from_word(w), R);
         nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
         nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
@@ -786,13 +789,13 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     if (mis) *P.misuse = 1u;
 }
 
-template <bool SLIP>
+template <bool SLIP, bool INT_ONLY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_hot(const KernelParams P, const StepIO IO) {
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     if ((g << 2) >= P.n) return;                                    // P.n is a multiple of 4 here
     const unsigned long long tick = *P.tick_in;                     // scalar load
     if (P.tick_out) publish_tick(P, tick, 1ull);
-    hot_group<SLIP>(P, IO, g, tick);
+    hot_group<SLIP, INT_ONLY>(P, IO, g, tick);
 }
 
 // =================================================================================================
