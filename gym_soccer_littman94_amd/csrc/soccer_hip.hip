@@ -362,7 +362,10 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
         std::vector<uint32_t> trans, code_tuple; std::vector<uint16_t> code_lut; bool fits = false;
         const std::string terr = build_transition_table(R, trans, code_lut, code_tuple, fits);
         if (!terr.empty()) { free_handle(h); return fail(nullptr, SOCCER_E_INVALID, "%s", terr.c_str()); }
-        const size_t smem = (trans.size() + kTblHead) * sizeof(uint32_t);
+        size_t smem = (trans.size() + kTblHead) * sizeof(uint32_t);
+        const size_t with_mix = ((smem + 15) & ~size_t(15)) + 2 * (size_t)R.nS * sizeof(uint2) + 2 * (((size_t)R.nS + 15) & ~size_t(15));
+        const bool mix_lds = with_mix <= 150 * 1024;
+        if (mix_lds) smem = with_mix;
         if (fits && smem <= 150 * 1024) {
             CREATE_TRY(hipMalloc(&h->d_trans, trans.size() * 4 + 16));
             CREATE_TRY(hipMemcpy(h->d_trans, trans.data(), trans.size() * 4, hipMemcpyHostToDevice));
@@ -370,7 +373,7 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
             CREATE_TRY(hipMemcpy(h->d_code_lut, code_lut.data(), code_lut.size() * 2, hipMemcpyHostToDevice));
             CREATE_TRY(hipMalloc(&h->d_code_tuple, code_tuple.size() * 4));
             CREATE_TRY(hipMemcpy(h->d_code_tuple, code_tuple.data(), code_tuple.size() * 4, hipMemcpyHostToDevice));
-            h->TT = TransTables{h->d_trans, h->d_code_lut, h->d_code_tuple, R.nS, (int32_t)code_tuple.size()};
+            h->TT = TransTables{h->d_trans, h->d_code_lut, h->d_code_tuple, R.nS, (int32_t)code_tuple.size(), mix_lds ? 1 : 0};
             h->table_smem = smem;
             hipError_t se = hipSuccess;
 #define RAISE_T(EV, DV) if (se == hipSuccess) se = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_table_kernel<EV, DV, false>), \

@@ -1003,6 +1003,8 @@ struct TransTables {
     const uint16_t* code_lut;     // [lut_len] tuple -> state code (0xFFFF unreachable)
     const uint32_t* code_tuple;   // [n_codes] state code -> row_a | col_a << 4 | row_b << 8 | col_b << 12 | poss << 16
     int32_t nS, n_codes;
+    int32_t mix_lds;              // the LDS has room for the two [nS][4] uint16 mixed-policy tables and the two
+                                  // int8[nS] fixed policies behind the table
 };
 constexpr int kTblBlock = 1024;          // one workgroup per CU shares one copy of the table
 
@@ -1015,7 +1017,9 @@ constexpr int kTblBlock = 1024;          // one workgroup per CU shares one copy
 // when the original action is, so the entry's NOOP tests are the reference's), and the outcome within the
 // combination by counting its scaled thresholds <= m (KernelParams::CB / sub, here `sub` in LDS).
 template <int E, bool DYN, bool GENERAL, bool SLIP>
-__device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_t* isd, const uint4* sub, uint32_t nS,
+__device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_t* isd, const uint4* sub,
+                                            const uint2* mix_a, const uint2* mix_b,
+                                            const int8_t* pol_a, const int8_t* pol_b, uint32_t nS,
                                             const KernelParams& P, const RolloutIO& IO,
                                             unsigned long long i0, unsigned long long tick0,
                                             uint32_t (&c)[E], uint32_t (&t)[E], uint32_t (&need)[E], int32_t (&acc)[E],
@@ -1050,18 +1054,18 @@ __device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_
                 const uint32_t ha = awords[j] & 0x7fffu, hb = (awords[j] >> 16) & 0x7fffu;
                 a = (ha * 5u) >> 15;
                 b = (hb * 5u) >> 15;
-                if (IO.mix_a) {
-                    const uint2 th = *reinterpret_cast<const uint2*>(IO.mix_a + 4u * s_now);
+                if (mix_a) {
+                    const uint2 th = mix_a[s_now];
                     a = (ha >= (th.x & 0xffffu)) + (ha >= (th.x >> 16)) + (ha >= (th.y & 0xffffu)) + (ha >= (th.y >> 16));
                 }
-                if (IO.mix_b) {
-                    const uint2 th = *reinterpret_cast<const uint2*>(IO.mix_b + 4u * s_now);
+                if (mix_b) {
+                    const uint2 th = mix_b[s_now];
                     b = (hb >= (th.x & 0xffffu)) + (hb >= (th.x >> 16)) + (hb >= (th.y & 0xffffu)) + (hb >= (th.y >> 16));
                 }
             }
             if (DYN) {
-                if (P.policy_a) a = (uint32_t)(uint8_t)P.policy_a[s_now];
-                if (P.policy_b) b = (uint32_t)(uint8_t)P.policy_b[s_now];
+                if (pol_a) a = (uint32_t)(uint8_t)pol_a[s_now];
+                if (pol_b) b = (uint32_t)(uint8_t)pol_b[s_now];
             }
             uint32_t e, kind, k;
             if (SLIP) {
@@ -1144,7 +1148,9 @@ __device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_
 }
 
 template <int E, bool DYN, bool SLIP>
-__device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const uint32_t* isd, const uint4* sub, const TransTables& TT,
+__device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const uint32_t* isd, const uint4* sub,
+                                                    const uint2* mix_a, const uint2* mix_b,
+                                                    const int8_t* pol_a, const int8_t* pol_b, const TransTables& TT,
                                                     const KernelParams& P, const RolloutIO& IO,
                                                     unsigned long long i0, unsigned long long tick0,
                                                     HistAcc<false>& hist, bool& any_misuse) {
@@ -1170,8 +1176,8 @@ __device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const
     uint32_t nonzero = 0u, fin_tot = 0u; int32_t rew_tot = 0;
 #pragma unroll
     for (int j = 0; j < E; ++j) acc[j] = 0;
-    if (special) table_steps<E, DYN, true, SLIP>(trans, isd, sub, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
-    else table_steps<E, DYN, false, SLIP>(trans, isd, sub, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
+    if (special) table_steps<E, DYN, true, SLIP>(trans, isd, sub, mix_a, mix_b, pol_a, pol_b, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
+    else table_steps<E, DYN, false, SLIP>(trans, isd, sub, mix_a, mix_b, pol_a, pol_b, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
     {   // codes back to tuples; lanes that were frozen on entry keep their bytes (rare: re-read them)
         PackB<E> ra, ca, rb, cb, ps, tt;
         ra.clear(); ca.clear(); rb.clear(); cb.clear(); ps.clear(); tt.clear();
@@ -1225,6 +1231,23 @@ __global__ __launch_bounds__(kTblBlock) void rollout_table_kernel(const KernelPa
         for (int i = threadIdx.x; i < n4; i += kTblBlock) dst[i] = src[i];
         for (int i = (n4 << 2) + threadIdx.x; i < TT.nS * 25; i += kTblBlock) trans[i] = TT.trans[i];
     }
+    // mixed-policy thresholds (config 5): one 8-byte row per state and player, behind the table when there is room
+    const uint2* mix_a = reinterpret_cast<const uint2*>(IO.mix_a);
+    const uint2* mix_b = reinterpret_cast<const uint2*>(IO.mix_b);
+    if (DYN && TT.mix_lds && IO.sample_actions) {
+        uint2* la = reinterpret_cast<uint2*>(trans + ((TT.nS * 25 + 3) & ~3));
+        uint2* lb = la + TT.nS;
+        if (mix_a) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) la[i] = mix_a[i]; mix_a = la; }
+        if (mix_b) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) lb[i] = mix_b[i]; mix_b = lb; }
+    }
+    // fixed policies of single-agent mode (int8[nS]), behind the mixed-policy rows
+    const int8_t* pol_a = P.policy_a; const int8_t* pol_b = P.policy_b;
+    if (DYN && TT.mix_lds) {
+        int8_t* la = reinterpret_cast<int8_t*>(trans + ((TT.nS * 25 + 3) & ~3) + 4 * TT.nS);
+        int8_t* lb = la + ((TT.nS + 15) & ~15);
+        if (pol_a) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) la[i] = pol_a[i]; pol_a = la; }
+        if (pol_b) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) lb[i] = pol_b[i]; pol_b = lb; }
+    }
     __syncthreads();
     const uint4* sub = reinterpret_cast<const uint4*>(smem + kIsdWords);
     const unsigned long long tick0 = *P.tick_in;
@@ -1235,10 +1258,10 @@ __global__ __launch_bounds__(kTblBlock) void rollout_table_kernel(const KernelPa
          g += (unsigned long long)gridDim.x * kTblBlock) {
         const unsigned long long i0 = g * E;
         if (E == 1 || i0 + E <= P.n) {
-            rollout_table_group<E, DYN, SLIP>(trans, smem, sub, TT, P, IO, i0, tick0, hist, any_misuse);
+            rollout_table_group<E, DYN, SLIP>(trans, smem, sub, mix_a, mix_b, pol_a, pol_b, TT, P, IO, i0, tick0, hist, any_misuse);
         } else {
             for (unsigned long long i = i0; i < P.n; ++i)
-                rollout_table_group<1, DYN, SLIP>(trans, smem, sub, TT, P, IO, i, tick0, hist, any_misuse);
+                rollout_table_group<1, DYN, SLIP>(trans, smem, sub, mix_a, mix_b, pol_a, pol_b, TT, P, IO, i, tick0, hist, any_misuse);
         }
     }
     if (any_misuse) *P.misuse = 1u;
