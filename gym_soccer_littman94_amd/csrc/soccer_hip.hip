@@ -485,9 +485,11 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
         if (lean) {                 // one 4-lane group per thread, as many workgroups as it takes
             const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
             const dim3 gh(static_cast<unsigned>(blocks));
-            if (h->slip && P.slip_int) hipLaunchKernelGGL((step_kernel_hot<true, true>), gh, b, 0, h->stream, P, io);
-            else if (h->slip) hipLaunchKernelGGL(step_kernel_hot<true>, gh, b, 0, h->stream, P, io);
-            else hipLaunchKernelGGL(step_kernel_hot<false>, gh, b, 0, h->stream, P, io);
+#define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, P.tick_in, P.n, P.first, P, io
+            if (h->slip && P.slip_int) hipLaunchKernelGGL((step_kernel_hot<true, true>), gh, b, 0, h->stream, HOT_ARGS);
+            else if (h->slip) hipLaunchKernelGGL(step_kernel_hot<true>, gh, b, 0, h->stream, HOT_ARGS);
+            else hipLaunchKernelGGL(step_kernel_hot<false>, gh, b, 0, h->stream, HOT_ARGS);
+#undef HOT_ARGS
         } else launch_step3<false, true, true>(h, P, io);
     }
     else if (vec) launch_step3<false, true, false>(h, P, io);
