@@ -705,6 +705,56 @@ def test_config4_full_size_eight_shards_equal_one_handle_and_invariants():
     np.testing.assert_array_equal(S_big["t"] <= T, True)
 
 
+def test_config3_full_size_step_path_equals_rollout_path_and_oracle_on_a_shard():
+    """BASELINE config 3 at full size: 2^20 lanes x 1000 steps of uniform-random joint actions.  The single-step
+    kernel (rule functions, what bench.py times) and the fused rollout (LDS transition table) are two
+    independent implementations: every output of every lane and step must agree, and the first 4 096 lanes
+    are checked against the CPU oracle step by step (results do not depend on the sharding)."""
+    import torch
+    n, K, sub = 1 << 20, 1000, 4096
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    acts = torch.randint(0, 5, (K, 2, n), dtype=torch.int8, device=dev, generator=g)
+    def bufs():
+        return (torch.empty((K, n), dtype=torch.int16, device=dev), torch.empty((K, n), dtype=torch.int8, device=dev),
+                torch.empty((K, n), dtype=torch.uint8, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev))
+    b1 = SoccerBatch(n, 5, 4, 0.0, seed=33, autoreset=True, step_stats=False)
+    b1.reset()
+    o1 = bufs()
+    for k in range(K):
+        b1.step_plain(acts[k, 0], acts[k, 1], o1[0][k], o1[1][k], o1[2][k], o1[3][k])
+    b1.sync()
+    b2 = SoccerBatch(n, 5, 4, 0.0, seed=33, autoreset=True)
+    b2.reset()
+    o2 = bufs()
+    a_flat = acts.view(K * 2, n)
+    b2.rollout(K, a_flat[0], a_flat[1], act_stride=2 * n, obs=o2[0], reward=o2[1], terminated=o2[2], truncated=o2[3], out_stride=n)
+    b2.sync()
+    for x, y, name in zip(o1, o2, ("obs", "reward", "terminated", "truncated")):
+        assert torch.equal(x, y), name
+    s1, s2 = b1.get_state(), b2.get_state()
+    for kx in s1:
+        np.testing.assert_array_equal(s1[kx], s2[kx], err_msg=kx)
+    assert b1.tick == b2.tick == K + 1
+    # size-independent properties of the outputs
+    fin = (o1[2] | o1[3]) != 0
+    assert int(o1[0].max()) < b1.nS and int(o1[0].min()) >= 1            # auto-reset: never the terminal index
+    assert bool(((o1[1] != 0) <= (o1[2] != 0)).all())                     # a reward only on a terminating step
+    hist = b2.stats()[0]
+    assert int(hist.sum()) == int(fin.sum()) and int(hist[2]) == int((o1[1] == 1).sum()) and int(hist[0]) == int((o1[1] == -1).sum())
+    # the oracle on the first shard
+    o = Oracle(5, 4, 0.0, n=sub, seed=33, autoreset=True)
+    o.reset()
+    A = acts[:, :, :sub].cpu().numpy()
+    O = o1[0][:, :sub].cpu().numpy().view(np.uint16); R = o1[1][:, :sub].cpu().numpy()
+    TE = o1[2][:, :sub].cpu().numpy(); TR = o1[3][:, :sub].cpu().numpy()
+    for k in range(K):
+        c = o.step(A[k, 0], A[k, 1])
+        np.testing.assert_array_equal(O[k], c["obs"]); np.testing.assert_array_equal(R[k], c["reward"])
+        np.testing.assert_array_equal(TE[k], c["terminated"]); np.testing.assert_array_equal(TR[k], c["truncated"])
+    b1.close(); b2.close()
+
+
 def test_graph_capture_replays_advance_the_tick():
     n, T = 8192, 6
     rng = np.random.default_rng(3)
