@@ -301,11 +301,39 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     {
         static const int cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
         bool ok = cfg->slip_prob != 0.0 && P.nb >= 1;
+        // Dyadic slips (0.5, 0.25, 0.75, 1.0 ...): every weight is a short binary fraction and every float64 sum
+        // of the lists is EXACT, so the nominal thresholds ARE the running sums and the integer comparison is the
+        // reference's comparison even when a draw sits exactly on a threshold.  Checked with error-free sums.
+        bool exact = true;
+        auto add_exact = [&](double a, double b) {                      // Fast2Sum: the rounding error of a + b
+            volatile double sum = a + b; volatile double bb = sum - a; volatile double err = (a - (sum - bb)) + (b - bb);
+            if (err != 0.0) exact = false;
+            return (double)sum;
+        };
+        {
+            static const int cls0[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+            double acc = 0.0;
+            for (int c = 0; c < 9; ++c) {
+                const double wc = P.w[cls0[c]];
+                if (wc == 0.0) continue;
+                double t2 = acc; for (int j = 0; j < 2; ++j) t2 = add_exact(t2, wc * 0.5);     // .5/.5 lists
+                double t4 = acc; for (int j = 0; j < 4; ++j) t4 = add_exact(t4, wc * 0.25);    // .25 x 4 lists
+                acc = add_exact(acc, wc);
+                if (t2 != acc || t4 != acc) exact = false;
+            }
+            volatile double s1 = cfg->slip_prob; volatile double om = 1 - s1;
+            if (add_exact(om, s1) != 1.0) exact = false;
+            // the weight products themselves must be exact too: compare with long double
+            const long double S = cfg->slip_prob, O = 1.0L - S;
+            if ((long double)P.w[0] != O * O || (long double)P.w[1] != O * S * 0.5L || (long double)P.w[2] != S * O * 0.5L ||
+                (long double)P.w[3] != S * S * 0.25L || (long double)(double)O != O) exact = false;
+        }
         auto scaled = [&](double t, uint32_t& out) {
             const double x = t * 0x1.0p30;                              // exact
             if (!(x >= 0.0) || x > 0x1.0p31) { ok = false; out = 0xFFFFFFFFu; return; }
             const double r = __builtin_nearbyint(x);
-            if (__builtin_fabs(x - r) < 0x1.0p-10 && r < 0x1.0p30) ok = false;   // a draw m = r (< 2^30) could sit on / next to it
+            // a draw m = r (< 2^30) could sit on / next to the threshold: only safe when the sums are exact
+            if (!exact && __builtin_fabs(x - r) < 0x1.0p-10 && r < 0x1.0p30) ok = false;
             out = (uint32_t)__builtin_ceil(x);
         };
         std::vector<uint4> sub(9, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));

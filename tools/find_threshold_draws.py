@@ -54,7 +54,7 @@ def thresholds(slip):
 def main():
     seed, n_lanes, ticks = 20241004, 1 << 22, 96
     res = {"seed": seed, "hits": []}
-    for slip in (0.2, 0.3):
+    for slip in (0.2, 0.3, 0.5):   # 0.5: dyadic, every float64 sum exact, thresholds ARE integers after scaling
         th = thresholds(slip)
         targets = {}
         for name, c, t in th:
