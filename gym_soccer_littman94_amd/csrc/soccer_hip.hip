@@ -503,7 +503,17 @@ static void launch_step3(soccer_handle* h, const KernelParams& P, const StepIO& 
 }
 static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& io, bool explicit_u, bool vec) {
     const bool shared = ((P.lane_offset + P.first) & 3ull) == 0ull;
-    if (explicit_u) {           // facade / test path: generic instantiations only
+    const bool policy_only = explicit_u && !io.u_step && !io.u_reset;       // fixed-policy handle, Philox draws
+    const bool lean0 = !io.prob_code && !io.final_obs && !io.last_return && !P.step_stats;
+    if (policy_only && vec && shared && lean0) {                            // the hot kernel with the policy lookup
+        const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
+        const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
+#define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, P.tick_in, P.n, P.first, P, io
+        if (h->slip && P.slip_int) hipLaunchKernelGGL((step_kernel_hot<true, true, true>), gh, b, 0, h->stream, HOT_ARGS);
+        else if (h->slip) hipLaunchKernelGGL((step_kernel_hot<true, false, true>), gh, b, 0, h->stream, HOT_ARGS);
+        else hipLaunchKernelGGL((step_kernel_hot<false, false, true>), gh, b, 0, h->stream, HOT_ARGS);
+#undef HOT_ARGS
+    } else if (explicit_u) {    // facade / test path: generic instantiations only
         if (vec && shared) launch_step3<true, true, true>(h, P, io); else launch_step3<true, false, false>(h, P, io);
     } else if (vec && shared) {
         // the hot instantiations; LEAN drops the code for prob_code / final_obs / last_return / step stats

@@ -698,7 +698,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
                 if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
             }
             StepResult R;
-            mis |= lane_step<SLIP, !EXPLICIT_U>(T, P, L, a_now, b_now, d, R);
+            // a caller-supplied uniform is an arbitrary double; without one the draw is the lane's Philox word
+            // (fixed-policy handles take this kernel too) and the integer slip decision applies
+            if (EXPLICIT_U && IO.u_step) mis |= lane_step<SLIP, false>(T, P, L, a_now, b_now, d, R);
+            else mis |= lane_step<SLIP, true>(T, P, L, a_now, b_now, d, R);
             nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
             nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
             nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
@@ -742,7 +745,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
 // one group of 4 lanes per thread, no grid-stride loop, no fallback or optional-output code at all.
 // Same lane loop as step_kernel; kept separate because a launch starts with a cold instruction cache
 // and every instruction that is not fetched counts (-0.4 us per launch against step_kernel<..., LEAN>).
-template <bool SLIP, bool INT_ONLY = false>
+// POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the current
+// observation (two more dependent table reads per lane); its action stream may be NULL.
+template <bool SLIP, bool INT_ONLY = false, bool POLICY = false>
 __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& IO, unsigned long long g, unsigned long long tick) {
     const unsigned long long i0 = P.first + (g << 2);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
@@ -753,8 +758,9 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     const uint32_t cb = *reinterpret_cast<const uint32_t*>(sp + 3 * P.state_stride + i0);
     const uint32_t ps = *reinterpret_cast<const uint32_t*>(sp + 4 * P.state_stride + i0);
     const uint32_t tt = *reinterpret_cast<const uint32_t*>(sp + 5 * P.state_stride + i0);
-    const uint32_t aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
-    const uint32_t ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
+    uint32_t aa = 0u, ab = 0u;
+    if (!POLICY || !P.policy_a) aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
+    if (!POLICY || !P.policy_b) ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
     // the thread's 4 lanes are exactly one Philox block; computed while the loads are in flight
     const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
     uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
@@ -769,8 +775,13 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
         L.B = make_pos(__builtin_amdgcn_ubfe(rb, sh, 8u), __builtin_amdgcn_ubfe(cb, sh, 8u), P.W);
         L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
         StepResult R;
-        mis |= lane_step<SLIP, true, INT_ONLY>(T, P, L, __builtin_amdgcn_ubfe(aa, sh, 8u), __builtin_amdgcn_ubfe(ab, sh, 8u),
-                               draw_from_word(w), R);
+        uint32_t a_now = __builtin_amdgcn_ubfe(aa, sh, 8u), b_now = __builtin_amdgcn_ubfe(ab, sh, 8u);
+        if (POLICY) {
+            const uint32_t s_now = obs_of(T, P, L.A, L.B, L.p);
+            if (P.policy_a) a_now = (uint32_t)(uint8_t)P.policy_a[s_now];
+            if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
+        }
+        mis |= lane_step<SLIP, true, INT_ONLY>(T, P, L, a_now, b_now, draw_from_word(w), R);
         nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
         nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
         nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
@@ -793,7 +804,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
 // the library is built with -mllvm -amdgpu-kernarg-preload-count=14, so they arrive in SGPRs at wave launch
 // and the nine data loads are issued without first waiting for a scalar load of the kernarg segment
 // (-0.3 .. -0.6 us per launch, tools/pipeline_lab.hip); the rest of P is fetched while they are in flight.
-template <bool SLIP, bool INT_ONLY = false>
+template <bool SLIP, bool INT_ONLY = false, bool POLICY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsigned long long state_stride,
                                                           const int8_t* act_a, const int8_t* act_b,
                                                           const unsigned long long* tick_in,
@@ -805,7 +816,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsign
     if (P.tick_out) publish_tick(P, tick, 1ull);
     KernelParams Q = P; Q.state = state; Q.state_stride = state_stride; Q.n = n; Q.first = first;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP, INT_ONLY>(Q, J, g, tick);
+    hot_group<SLIP, INT_ONLY, POLICY>(Q, J, g, tick);
 }
 
 // =================================================================================================

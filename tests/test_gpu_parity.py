@@ -462,6 +462,36 @@ def test_hot_instantiation_plain_step_vs_oracle(slip, n, off):
     b.close()
 
 
+@pytest.mark.parametrize("slip,fixed,n", [(0.0, "player_b", 16384), (0.2, "player_a", 16384 + 3), (0.1, "player_b", 8192), (0.5, "player_a", 4096)])
+def test_hot_instantiation_with_fixed_policy_vs_oracle(slip, fixed, n):
+    """Single-agent handles through the plain 8-argument batched_step (the fixed side's stream is NULL): the
+    hot kernel with the policy lookup, every lane and step against the oracle, which is handed the fixed
+    side's actions gathered on the host from the current observations."""
+    steps = 120
+    rng = np.random.default_rng(13)
+    policy = rng.integers(0, 5, size=761).astype(np.int8)
+    b = SoccerBatch(n, 5, 4, slip, seed=17, autoreset=True, step_stats=False)
+    b.set_policy(fixed, policy)
+    o = Oracle(5, 4, slip, n=n, seed=17, autoreset=True)
+    obs = b.alloc(n, np.uint16); rew = b.alloc(n, np.int8); term = b.alloc(n, np.uint8); trunc = b.alloc(n, np.uint8)
+    act = b.alloc(n, np.int8)
+    b.reset(obs=obs); cur = o.reset()
+    np.testing.assert_array_equal(obs.download(), cur)
+    for k in range(steps):
+        a = rng.integers(0, 5, n, dtype=np.int8)
+        act.upload(a)
+        if fixed == "player_b":
+            b.step_plain(act, None, obs, rew, term, trunc); c = o.step(a, policy[cur])
+        else:
+            b.step_plain(None, act, obs, rew, term, trunc); c = o.step(policy[cur], a)
+        np.testing.assert_array_equal(obs.download(), c["obs"], err_msg="obs step %d" % k)
+        np.testing.assert_array_equal(rew.download(), c["reward"]); np.testing.assert_array_equal(term.download(), c["terminated"])
+        np.testing.assert_array_equal(trunc.download(), c["truncated"])
+        cur = c["obs"]
+    assert_state_equal(b, o)
+    b.close()
+
+
 def test_no_autoreset_freezes_finished_lanes_and_flags_misuse():
     n = 4096
     rng = np.random.default_rng(7)
