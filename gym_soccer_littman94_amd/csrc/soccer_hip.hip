@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -859,12 +860,15 @@ static int scalar_call(soccer_handle* h, const char* what, uint32_t op, soccer_s
     else hipLaunchKernelGGL(scalar_kernel<false>, dim3(1), dim3(64), 0, h->stream, P, k);
     HIP_TRY(h, hipGetLastError());
     volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->rec_host);
+    const auto t_start = std::chrono::steady_clock::now();
     for (uint32_t spins = 0; *flag != k.seq; ++spins) {
         __builtin_ia32_pause();
-        if ((spins & 0xfffffu) == 0xfffffu) {                            // every ~10 ms: has the stream died?
+        if ((spins & 0xfffffu) == 0xfffffu) {                            // every few ms: has the stream died?
             const hipError_t e = hipStreamQuery(h->stream);
             if (e != hipSuccess && e != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "%s: %s", what, hipGetErrorString(e));
             if (e == hipSuccess && *flag != k.seq) return fail(h, SOCCER_E_HIP, "%s: the kernel finished without publishing its record", what);
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
+                return fail(h, SOCCER_E_HIP, "%s: no result after 30 s (is another stream hogging the device?)", what);
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
