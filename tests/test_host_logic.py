@@ -90,3 +90,33 @@ def test_closed_form_state_numbering_matches_reference_tables(path):
     interior = (ya > 0) & (ya < W - 1) & (yb > 0) & (yb < W - 1) & ~((xa == xb) & (ya == yb))
     np.testing.assert_array_equal(live, interior)
     assert (lut[kind == 2] == 0).all() and (lut[kind == 0] == 0xFFFF).all()
+
+
+def test_threshold_draw_fixture_is_what_it_claims():
+    """tests/golden/threshold_draws.json (tools/find_threshold_draws.py): every recorded draw is the spec's Philox
+    word of that (lane, tick) and sits on, or one below, a scaled slip threshold formed with the kernels' float64
+    operations."""
+    import json
+    import os
+    import numpy as np
+    from oracle.oracle import philox4x32_10
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "threshold_draws.json")))
+    seed = d["seed"]
+    assert len(d["hits"]) >= 50 and {h["slip"] for h in d["hits"]} == {0.2, 0.3, 0.5}
+    cls = [0, 1, 1, 2, 2, 3, 3, 3, 3]
+    for h in d["hits"]:
+        q = h["lane"] >> 2
+        w = philox4x32_10([q & 0xffffffff, q >> 32, h["tick"], 0], [seed & 0xffffffff, seed >> 32])
+        assert int(w[h["lane"] & 3]) >> 2 == h["m"]
+        s = np.float64(h["slip"]); om = np.float64(1) - s
+        wt = [om * om, (om * s) * 0.5, (s * om) * 0.5, (s * s) * 0.25]
+        acc, th = np.float64(0), {}
+        for c in range(9):
+            S = acc; acc = acc + wt[cls[c]]
+            th[("end", c)] = acc; th[("two", c)] = S + wt[cls[c]] * 0.5
+            t = S + wt[cls[c]] * 0.25; th[("four1", c)] = t
+            t = t + wt[cls[c]] * 0.25; th[("four2", c)] = t
+            t = t + wt[cls[c]] * 0.25; th[("four3", c)] = t
+        for name, c in h["thresholds"]:
+            cb = int(np.ceil(float(th[(name, c)]) * 2.0 ** 30))
+            assert h["m"] in (cb - 1, cb)
