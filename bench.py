@@ -258,7 +258,7 @@ def main():
                        "parallelism": "independent lane shards x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "soccer::step_kernel_hot<%s>" % ("true, true|false" if args.slip else "false, false"), "launch_us": launch_s * 1e6,
+                         "kernel": "soccer::step_kernel_hot<%s>" % ("true, true|false, false" if args.slip else "false, false, false"), "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
             "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
                          "gathered_last_returns": int(gathered.numel()),
