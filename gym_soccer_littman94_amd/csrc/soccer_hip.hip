@@ -861,12 +861,14 @@ static int scalar_call(soccer_handle* h, const char* what, uint32_t op, soccer_s
     HIP_TRY(h, hipGetLastError());
     volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->rec_host);
     const auto t_start = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0; *flag != k.seq; ++spins) {
+    // complete record: word 0 == seq and the high half of word 3 == seq's low half (both ends of the one store)
+    auto landed = [&]() { return flag[0] == k.seq && (flag[3] >> 16) == (k.seq & 0xffffu); };
+    for (uint32_t spins = 0; !landed(); ++spins) {
         __builtin_ia32_pause();
         if ((spins & 0xfffffu) == 0xfffffu) {                            // every few ms: has the stream died?
             const hipError_t e = hipStreamQuery(h->stream);
             if (e != hipSuccess && e != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "%s: %s", what, hipGetErrorString(e));
-            if (e == hipSuccess && *flag != k.seq) return fail(h, SOCCER_E_HIP, "%s: the kernel finished without publishing its record", what);
+            if (e == hipSuccess && !landed()) return fail(h, SOCCER_E_HIP, "%s: the kernel finished without publishing its record", what);
             if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
                 return fail(h, SOCCER_E_HIP, "%s: no result after 30 s (is another stream hogging the device?)", what);
         }
@@ -878,7 +880,7 @@ static int scalar_call(soccer_handle* h, const char* what, uint32_t op, soccer_s
     io->terminated = (res >> 24) & 1u; io->truncated = (res >> 25) & 1u; io->prob_code = (uint8_t)(res >> 26);
     io->row_a = (int8_t)(npos & 0xffu); io->col_a = (int8_t)((npos >> 8) & 0xffu);
     io->row_b = (int8_t)((npos >> 16) & 0xffu); io->col_b = (int8_t)(npos >> 24);
-    io->poss = nm & 1u; io->needs_reset = (nm >> 1) & 1u; io->t = (uint8_t)(nm >> 8);
+    io->poss = nm & 1u; io->needs_reset = (nm >> 1) & 1u; io->t = (uint8_t)((nm >> 8) & 0xffu);
     return SOCCER_OK;
 }
 
