@@ -814,6 +814,40 @@ def test_graph_capture_replays_advance_the_tick():
     b.close()
 
 
+@pytest.mark.parametrize("slip", [0.0, 0.2])
+def test_graph_capture_of_rollouts_and_policy_steps(slip):
+    """A captured sequence mixing two fused rollouts (LDS transition table) and two single-agent steps (hot kernel
+    with the policy lookup) replays exactly like the eager sequence on the oracle; ticks advance per replay."""
+    n, T = 4096, 9
+    rng = np.random.default_rng(8)
+    policy = rng.integers(0, 5, size=761).astype(np.int8)
+    acts = rng.integers(0, 5, size=(2 * T + 2, n), dtype=np.int8)
+    b = SoccerBatch(n, 5, 4, slip, seed=2, autoreset=True, step_stats=False); b.set_policy("player_b", policy)
+    o = Oracle(5, 4, slip, n=n, seed=2, autoreset=True)
+    b.reset(); cur = o.reset()
+    A = b.alloc(acts.shape, np.int8).upload(acts)
+    obs = b.alloc((2 * T + 2, n), np.uint16); rew = b.alloc((2 * T + 2, n), np.int8)
+    term = b.alloc((2 * T + 2, n), np.uint8); trunc = b.alloc((2 * T + 2, n), np.uint8)
+    b.graph_begin()
+    b.rollout(T, A.row(0), None, act_stride=n, obs=obs.row(0), reward=rew.row(0), terminated=term.row(0), truncated=trunc.row(0), out_stride=n)
+    b.step_plain(A.row(T), None, obs.row(T), rew.row(T), term.row(T), trunc.row(T))
+    b.rollout(T, A.row(T + 1), None, act_stride=n, obs=obs.row(T + 1), reward=rew.row(T + 1), terminated=term.row(T + 1),
+              truncated=trunc.row(T + 1), out_stride=n)
+    b.step_plain(A.row(2 * T + 1), None, obs.row(2 * T + 1), rew.row(2 * T + 1), term.row(2 * T + 1), trunc.row(2 * T + 1))
+    g = b.graph_end()
+    for rep in range(3):
+        b.graph_launch(g, 1)
+        O, R, TE = obs.download(), rew.download(), term.download()
+        for k in range(2 * T + 2):
+            c = o.step(acts[k], policy[cur])
+            np.testing.assert_array_equal(O[k], c["obs"], err_msg="rep %d step %d" % (rep, k))
+            np.testing.assert_array_equal(R[k], c["reward"]); np.testing.assert_array_equal(TE[k], c["terminated"])
+            cur = c["obs"]
+    assert b.tick == o.tick == 1 + 3 * (2 * T + 2)
+    assert_state_equal(b, o)
+    b.graph_destroy(g); b.close()
+
+
 def test_state_injection_rejects_unreachable_tuples():
     b = SoccerBatch(2, 5, 4, 0.0)
     with pytest.raises(KeyError):
