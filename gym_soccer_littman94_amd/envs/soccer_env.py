@@ -267,6 +267,13 @@ class SoccerSimultaneousEnv:
         for ln in lines:
             print(ln)
         print(f"Ball possession: {'A' if p == 0 else 'B'}")
+        if self.lastaction:                                              # :462-473
+            if self.multiagent:
+                print("Last actions: A: %s, B: %s" % (self.ACTION_STRING[self.lastaction['player_a']],
+                                                      self.ACTION_STRING[self.lastaction['player_b']]))
+            else:
+                who = self.return_agent[0]
+                print("Last action: %s: %s" % ('A' if who == 'player_a' else 'B', self.ACTION_STRING[self.lastaction[who]]))
         carrier_col, carrier_row = (ya, xa) if p == 0 else (yb, xb)
         if carrier_row in self.goal_rows and carrier_col in self.goal_cols:
             scorer_is_a = carrier_col == W - 1
