@@ -120,3 +120,22 @@ def test_threshold_draw_fixture_is_what_it_claims():
         for name, c in h["thresholds"]:
             cb = int(np.ceil(float(th[(name, c)]) * 2.0 ** 30))
             assert h["m"] in (cb - 1, cb)
+
+
+def test_install_as_gym_soccer_aliases_the_reference_import_names():
+    import sys
+    import gym_soccer_littman94_amd as gsa
+    assert "gym_soccer" not in sys.modules
+    gsa.install_as_gym_soccer()
+    try:
+        from gym_soccer.envs import SoccerSimultaneousEnv
+        from gym_soccer.envs.soccer_simultaneous_env import SoccerSimultaneousEnv as E2
+        from gym_soccer.utils.planners import modified_policy_iteration, policy_iteration, value_iteration
+        from gym_soccer.utils.policies import get_random_policy, get_stand_policy
+        assert SoccerSimultaneousEnv is gsa.SoccerSimultaneousEnv is E2
+        assert value_iteration is gsa.planners.value_iteration and policy_iteration and modified_policy_iteration
+        assert get_stand_policy(3) == {0: 0, 1: 0, 2: 0} and len(get_random_policy(5, 5, 1)) == 5
+        gsa.install_as_gym_soccer()                  # idempotent over its own alias
+    finally:
+        for k in [k for k in sys.modules if k == "gym_soccer" or k.startswith("gym_soccer.")]:
+            del sys.modules[k]
