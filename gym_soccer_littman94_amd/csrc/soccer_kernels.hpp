@@ -28,6 +28,12 @@
 namespace soccer {
 
 constexpr int kBlock = 256;
+#ifndef SOCCER_HOT_UNROLL
+#define SOCCER_HOT_UNROLL 4          // lane-loop unroll of step_kernel_hot<false>: see DESIGN.md section 4
+#endif
+#ifndef SOCCER_HOT_UNROLL_SLIP
+#define SOCCER_HOT_UNROLL_SLIP 4
+#endif
 constexpr int kHistSlots = 16384;        // >= waves of the largest grid (8 blocks x 4 waves x 512 CUs)
 constexpr int kHistStride = 4;           // u64 per slot: return -1, 0, +1, pad
 constexpr int kIsdWords = 16;            // LDS: 4 ISD entries x (A, B, poss|obs<<16, pad)
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
 // and every instruction that is not fetched counts (-0.4 us per launch against step_kernel<..., LEAN>).
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the current
 // observation (two more dependent table reads per lane); its action stream may be NULL.
-template <bool SLIP, bool INT_ONLY = false, bool POLICY = false>
+template <bool SLIP, bool INT_ONLY = false, bool POLICY = false, int UNROLL = 1>
 __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& IO, unsigned long long g, unsigned long long tick) {
     const unsigned long long i0 = P.first + (g << 2);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
@@ -765,7 +771,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
     uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
     bool mis = false;
-#pragma unroll 1
+#pragma unroll UNROLL
     for (int j = 0; j < 4; ++j) {
         const uint32_t w = j & 2 ? (j & 1 ? blk.w[3] : blk.w[2]) : (j & 1 ? blk.w[1] : blk.w[0]);
         const uint32_t sh = 8u * (uint32_t)j;
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsign
     if (P.tick_out) publish_tick(P, tick, 1ull);
     KernelParams Q = P; Q.state = state; Q.state_stride = state_stride; Q.n = n; Q.first = first;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP, INT_ONLY, POLICY>(Q, J, g, tick);
+    hot_group<SLIP, INT_ONLY, POLICY, SLIP ? SOCCER_HOT_UNROLL_SLIP : SOCCER_HOT_UNROLL>(Q, J, g, tick);
 }
 
 // =================================================================================================

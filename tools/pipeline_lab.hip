@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock) void k_plain(const KernelParams P, const St
 // Kernel-argument preload experiment: the arguments the first loads depend on come first, as scalars, so that
 // (built with -mllvm -amdgpu-kernarg-preload-count=14) they arrive in SGPRs at wave launch and the data loads
 // can be issued without waiting for the scalar load of the kernarg segment.
-template <bool SLIP>
+template <bool SLIP, int UNROLL = 1>
 __global__ __launch_bounds__(kBlock) void k_plain_pre(uint8_t* state, unsigned long long stride, const int8_t* act_a, const int8_t* act_b,
                                                       unsigned long long tick, unsigned long long n, unsigned long long first,
                                                       const KernelParams P, const StepIO IO) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void k_plain_pre(uint8_t* state, unsigned l
     if ((g << 2) >= n) return;
     KernelParams Q = P; Q.state = state; Q.state_stride = stride; Q.n = n; Q.first = first;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP>(Q, J, g, tick);
+    hot_group<SLIP, false, false, UNROLL>(Q, J, g, tick);
 }
 
 // STRIDE: uint32 words between consecutive workgroups' counters (1 = packed, 16 = one 64-byte line each)
@@ -107,6 +107,13 @@ int main(int argc, char** argv) {
     timed("plain, normal launches", [&](int k) { hipLaunchKernelGGL(k_plain<false>, dim3(1024), dim3(256), 0, st, P, io_for(k), (unsigned long long)k); }, &ref);
     timed("plain, leading scalar args (kernarg preload)", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL(k_plain_pre<false>, dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload + lane loop unrolled x2", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 2>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload + lane loop unrolled x4", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 4>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload (again)", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 1>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    if (argc > 2) return 0;
     timed("chain (packed flags), normal launches", [&](int k) { hipLaunchKernelGGL((k_chain<false, 1>), dim3(1024), dim3(256), 0, st, P, io_for(k), (unsigned long long)k, d_done, (uint32_t)k, d_err); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
     timed("chain (packed flags), any-order launches", [&](int k) { hipExtLaunchKernelGGL((k_chain<false, 1>), dim3(1024), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, P, io_for(k), (unsigned long long)k, d_done, (uint32_t)k, d_err); }, &got);
