@@ -754,7 +754,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the current
 // observation (two more dependent table reads per lane); its action stream may be NULL.
 template <bool SLIP, bool INT_ONLY = false, bool POLICY = false, int UNROLL = 1>
-__device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& IO, unsigned long long g, unsigned long long tick) {
+__device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& IO, unsigned long long g,
+                                          const unsigned long long* tick_ptr, unsigned long long tick_val) {
     const unsigned long long i0 = P.first + (g << 2);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
     const uint8_t* sp = P.state;
@@ -767,6 +768,10 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     uint32_t aa = 0u, ab = 0u;
     if (!POLICY || !P.policy_a) aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
     if (!POLICY || !P.policy_b) ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
+    // The tick comes from device memory (graph replays cannot change kernel arguments).  It is read AFTER the
+    // eight data loads above have been issued: read first, its scalar-cache miss (~1 us) sat in front of them.
+    const unsigned long long tick = tick_ptr ? *tick_ptr : tick_val;
+    if (tick_ptr && P.tick_out) publish_tick(P, tick, 1ull);
     // the thread's 4 lanes are exactly one Philox block; computed while the loads are in flight
     const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
     uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
@@ -818,11 +823,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsign
                                                           const KernelParams P, const StepIO IO) {
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     if ((g << 2) >= n) return;                                      // n is a multiple of 4 here
-    const unsigned long long tick = *tick_in;                       // scalar load
-    if (P.tick_out) publish_tick(P, tick, 1ull);
     KernelParams Q = P; Q.state = state; Q.state_stride = state_stride; Q.n = n; Q.first = first;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP, INT_ONLY, POLICY, SLIP ? SOCCER_HOT_UNROLL_SLIP : SOCCER_HOT_UNROLL>(Q, J, g, tick);
+    hot_group<SLIP, INT_ONLY, POLICY, SLIP ? SOCCER_HOT_UNROLL_SLIP : SOCCER_HOT_UNROLL>(Q, J, g, tick_in, 0ull);
 }
 
 // =================================================================================================

@@ -20,7 +20,7 @@ template <bool SLIP>
 __global__ __launch_bounds__(kBlock) void k_plain(const KernelParams P, const StepIO IO, unsigned long long tick) {
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     if ((g << 2) >= P.n) return;
-    hot_group<SLIP>(P, IO, g, tick);
+    hot_group<SLIP>(P, IO, g, nullptr, tick);
 }
 
 // Kernel-argument preload experiment: the arguments the first loads depend on come first, as scalars, so that
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void k_plain_pre(uint8_t* state, unsigned l
     if ((g << 2) >= n) return;
     KernelParams Q = P; Q.state = state; Q.state_stride = stride; Q.n = n; Q.first = first;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP, false, false, UNROLL>(Q, J, g, tick);
+    hot_group<SLIP, false, false, UNROLL>(Q, J, g, nullptr, tick);
 }
 
 // STRIDE: uint32 words between consecutive workgroups' counters (1 = packed, 16 = one 64-byte line each)
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_chain(const KernelParams P, const St
     }
     __syncthreads();
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    if ((g << 2) < P.n) hot_group<SLIP>(P, IO, g, tick);
+    if ((g << 2) < P.n) hot_group<SLIP>(P, IO, g, nullptr, tick);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(mine, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
