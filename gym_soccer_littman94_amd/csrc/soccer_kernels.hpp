@@ -651,8 +651,8 @@ template <bool SLIP, bool EXPLICIT_U, bool VEC, bool SHARED, int UNROLL = 1, int
 __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const StepIO IO) {
     const unsigned long long groups = (P.n + 3) >> 2;
     const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
-    const unsigned long long tick = *P.tick_in;                 // scalar load
-    if (P.tick_out) publish_tick(P, tick, 1ull);
+    const unsigned long long tick = *P.tick_in;                 // scalar load; published at the end so that its miss
+                                                                // does not sit in front of the first data loads
     // the episode histogram of single steps is opt-in (SOCCER_F_STEP_STATS): counting, the wave
     // reduction and the slot update cost ~0.5 us of a ~9 us launch
     const bool stats = !LEAN && P.step_stats != 0u;
@@ -745,6 +745,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
     }
     if (mis) *P.misuse = 1u;
     if (stats) hist.flush(P);
+    if (P.tick_out) publish_tick(P, tick, 1ull);
 }
 
 // The instantiation every Philox-driven, dword-aligned, 4-outputs-only step takes (bench.py's path):
