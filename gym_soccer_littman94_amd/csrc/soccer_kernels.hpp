@@ -439,6 +439,17 @@ template <int E> struct PackB {
         if constexpr (E == 4) { *reinterpret_cast<uint32_t*>(p) = w[0]; }
         else { *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]); }
     }
+    // streaming variants (trajectory outputs / action inputs: touched once)
+    __device__ __forceinline__ void load_nt(const void* base, unsigned long long i) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(base) + i);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) w[k] = __builtin_nontemporal_load(p + k);
+    }
+    __device__ __forceinline__ void store_nt(void* base, unsigned long long i) const {
+        uint32_t* p = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(base) + i);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) __builtin_nontemporal_store(w[k], p + k);
+    }
 };
 template <> struct PackB<1> {
     uint32_t b;
@@ -447,6 +458,8 @@ template <> struct PackB<1> {
     __device__ __forceinline__ void put(int, uint32_t v) { b = v; }
     __device__ __forceinline__ void load(const void* base, unsigned long long i) { b = static_cast<const uint8_t*>(base)[i]; }
     __device__ __forceinline__ void store(void* base, unsigned long long i) const { static_cast<uint8_t*>(base)[i] = (uint8_t)b; }
+    __device__ __forceinline__ void load_nt(const void* base, unsigned long long i) { load(base, i); }
+    __device__ __forceinline__ void store_nt(void* base, unsigned long long i) const { store(base, i); }
 };
 
 // E consecutive uint16 of one stream, as E/2 dwords; values must already fit 16 bits
@@ -463,12 +476,18 @@ template <int E> struct PackH {
         if constexpr (E == 4) { *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]); }
         else { *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]); }
     }
+    __device__ __forceinline__ void store_nt(uint16_t* base, unsigned long long i) const {
+        uint32_t* p = reinterpret_cast<uint32_t*>(base + i);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) __builtin_nontemporal_store(w[k], p + k);
+    }
 };
 template <> struct PackH<1> {
     uint32_t h;
     __device__ __forceinline__ void clear() { h = 0u; }
     __device__ __forceinline__ void put(int, uint32_t v) { h = v; }
     __device__ __forceinline__ void store(uint16_t* base, unsigned long long i) const { base[i] = (uint16_t)h; }
+    __device__ __forceinline__ void store_nt(uint16_t* base, unsigned long long i) const { store(base, i); }
 };
 
 // E consecutive int32 accumulators (return_sum / episode_count), read-modify-write
@@ -767,8 +786,13 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     const uint32_t ps = *reinterpret_cast<const uint32_t*>(sp + 4 * P.state_stride + i0);
     const uint32_t tt = *reinterpret_cast<const uint32_t*>(sp + 5 * P.state_stride + i0);
     uint32_t aa = 0u, ab = 0u;
+#ifndef SOCCER_TEMPORAL_IO
+    if (!POLICY || !P.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
+    if (!POLICY || !P.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
+#else
     if (!POLICY || !P.policy_a) aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
     if (!POLICY || !P.policy_b) ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
+#endif
     // The tick comes from device memory (graph replays cannot change kernel arguments).  It is read AFTER the
     // eight data loads above have been issued: read first, its scalar-cache miss (~1 us) sat in front of them.
     const unsigned long long tick = tick_ptr ? *tick_ptr : tick_val;
@@ -805,10 +829,20 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     *reinterpret_cast<uint32_t*>(sw + i0) = nra; *reinterpret_cast<uint32_t*>(sw + P.state_stride + i0) = nca;
     *reinterpret_cast<uint32_t*>(sw + 2 * P.state_stride + i0) = nrb; *reinterpret_cast<uint32_t*>(sw + 3 * P.state_stride + i0) = ncb;
     *reinterpret_cast<uint32_t*>(sw + 4 * P.state_stride + i0) = nps; *reinterpret_cast<uint32_t*>(sw + 5 * P.state_stride + i0) = ntt;
+    // Results are written once and never re-read by these kernels, actions are read once: non-temporal accesses
+    // keep them from displacing the resident state in L2 / Infinity Cache (7.66 -> 6.97 us per launch).
+#ifndef SOCCER_TEMPORAL_IO
+    if (IO.obs) { __builtin_nontemporal_store(o_lo, reinterpret_cast<uint32_t*>(IO.obs + i0));
+                  __builtin_nontemporal_store(o_hi, reinterpret_cast<uint32_t*>(IO.obs + i0) + 1); }
+    if (IO.reward) __builtin_nontemporal_store(o_rew, reinterpret_cast<uint32_t*>(IO.reward + i0));
+    if (IO.terminated) __builtin_nontemporal_store(o_term, reinterpret_cast<uint32_t*>(IO.terminated + i0));
+    if (IO.truncated) __builtin_nontemporal_store(o_trunc, reinterpret_cast<uint32_t*>(IO.truncated + i0));
+#else
     if (IO.obs) *reinterpret_cast<uint2*>(IO.obs + i0) = make_uint2(o_lo, o_hi);
     if (IO.reward) *reinterpret_cast<uint32_t*>(IO.reward + i0) = o_rew;
     if (IO.terminated) *reinterpret_cast<uint32_t*>(IO.terminated + i0) = o_term;
     if (IO.truncated) *reinterpret_cast<uint32_t*>(IO.truncated + i0) = o_trunc;
+#endif
     if (mis) *P.misuse = 1u;
 }
 
