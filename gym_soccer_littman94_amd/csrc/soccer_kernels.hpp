@@ -964,8 +964,8 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
     PackB<E> aa, ab; aa.clear(); ab.clear();
     const bool sample = DYN && IO.sample_actions;
     if (!sample) {
-        if (!DYN || IO.act_a) aa.load(IO.act_a, i0);
-        if (!DYN || IO.act_b) ab.load(IO.act_b, i0);
+        if (!DYN || IO.act_a) aa.load_nt(IO.act_a, i0);
+        if (!DYN || IO.act_b) ab.load_nt(IO.act_b, i0);
     }
     // the observation of the current tuple is carried along when an action depends on it
     const bool fixed = DYN && (P.policy_a != nullptr || P.policy_b != nullptr ||    // single-agent mode
@@ -977,8 +977,8 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         const unsigned long long tick = tick0 + (unsigned long long)s;
         PackB<E> naa = aa, nab = ab;
         if (!sample && s + 1 < IO.n_steps) {                            // prefetch the next step's actions
-            if (!DYN || IO.act_a) naa.load(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
-            if (!DYN || IO.act_b) nab.load(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
+            if (!DYN || IO.act_a) naa.load_nt(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
+            if (!DYN || IO.act_b) nab.load_nt(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
         }
         uint32_t words[E], awords[E];
         lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
@@ -1013,10 +1013,10 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
             ret[j] += R.reward; eps[j] += (int32_t)R.finished; nonzero += (uint32_t)R.reward & 1u;
         }
         const long long off = (long long)s * IO.out_stride;
-        if (IO.obs) o_obs.store(IO.obs + off, i0);
-        if (IO.reward) o_rew.store(IO.reward + off, i0);
-        if (IO.terminated) o_term.store(IO.terminated + off, i0);
-        if (IO.truncated) o_trunc.store(IO.truncated + off, i0);
+        if (IO.obs) o_obs.store_nt(IO.obs + off, i0);
+        if (IO.reward) o_rew.store_nt(IO.reward + off, i0);
+        if (IO.terminated) o_term.store_nt(IO.terminated + off, i0);
+        if (IO.truncated) o_trunc.store_nt(IO.truncated + off, i0);
         aa = naa; ab = nab;
     }
     S.store(P, i0);
@@ -1097,15 +1097,15 @@ __device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_
     PackB<E> aa, ab; aa.clear(); ab.clear();
     const bool sample = DYN && IO.sample_actions;
     if (!sample) {
-        if (!DYN || IO.act_a) aa.load(IO.act_a, i0);
-        if (!DYN || IO.act_b) ab.load(IO.act_b, i0);
+        if (!DYN || IO.act_a) aa.load_nt(IO.act_a, i0);
+        if (!DYN || IO.act_b) ab.load_nt(IO.act_b, i0);
     }
     for (int s = 0; s < IO.n_steps; ++s) {
         const unsigned long long tick = tick0 + (unsigned long long)s;
         PackB<E> naa = aa, nab = ab;
         if (!sample && s + 1 < IO.n_steps) {                            // prefetch the next step's actions
-            if (!DYN || IO.act_a) naa.load(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
-            if (!DYN || IO.act_b) nab.load(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
+            if (!DYN || IO.act_a) naa.load_nt(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
+            if (!DYN || IO.act_b) nab.load_nt(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
         }
         uint32_t words[E], awords[E];
         lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
@@ -1208,10 +1208,10 @@ __device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_
             }
         }
         const long long off = (long long)s * IO.out_stride;
-        if (IO.obs) o_obs.store(IO.obs + off, i0);
-        if (IO.reward) o_rew.store(IO.reward + off, i0);
-        if (IO.terminated) o_term.store(IO.terminated + off, i0);
-        if (IO.truncated) o_trunc.store(IO.truncated + off, i0);
+        if (IO.obs) o_obs.store_nt(IO.obs + off, i0);
+        if (IO.reward) o_rew.store_nt(IO.reward + off, i0);
+        if (IO.terminated) o_term.store_nt(IO.terminated + off, i0);
+        if (IO.truncated) o_trunc.store_nt(IO.truncated + off, i0);
         aa = naa; ab = nab;
     }
 }
