@@ -37,6 +37,17 @@ __global__ __launch_bounds__(kBlock) void k_plain_pre(uint8_t* state, unsigned l
     hot_group<SLIP, false, false, UNROLL>(Q, J, g, nullptr, tick);
 }
 
+template <bool SLIP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_plain_blk(uint8_t* state, unsigned long long stride, const int8_t* act_a, const int8_t* act_b,
+                                                     unsigned long long tick, unsigned long long n, unsigned long long first,
+                                                     const KernelParams P, const StepIO IO) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if ((g << 2) >= n) return;
+    KernelParams Q = P; Q.state = state; Q.state_stride = stride; Q.n = n; Q.first = first;
+    StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
+    hot_group<SLIP, false, false, 4>(Q, J, g, nullptr, tick);
+}
+
 // STRIDE: uint32 words between consecutive workgroups' counters (1 = packed, 16 = one 64-byte line each)
 template <bool SLIP, int STRIDE>
 __global__ __launch_bounds__(kBlock) void k_chain(const KernelParams P, const StepIO IO, unsigned long long tick,
@@ -110,6 +121,12 @@ int main(int argc, char** argv) {
     timed("preload + lane loop unrolled x2", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 2>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
     timed("preload + lane loop unrolled x4", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 4>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload x4, 128-thread workgroups", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_blk<false, 128>), dim3(2048), dim3(128), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload x4, 512-thread workgroups", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_blk<false, 512>), dim3(512), dim3(512), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload x4, 1024-thread workgroups", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_blk<false, 1024>), dim3(256), dim3(1024), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
     timed("preload (again)", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 1>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
