@@ -48,6 +48,104 @@ __global__ __launch_bounds__(BLOCK) void k_plain_blk(uint8_t* state, unsigned lo
     hot_group<SLIP, false, false, 4>(Q, J, g, nullptr, tick);
 }
 
+// Phase-structured variant of the slip-0 hot body: all eight move-table reads of the thread's four lanes are issued
+// together, then the four observation reads, and auto-reset / frozen lanes are patched afterwards in one place
+// (one group of four ISD reads) instead of a divergent branch per lane.
+__device__ __forceinline__ void hot_group_phased(const KernelParams& P, const StepIO& IO, unsigned long long g, unsigned long long tick) {
+    const unsigned long long i0 = P.first + (g << 2);
+    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
+    const uint8_t* sp = P.state;
+    const uint32_t ra = *reinterpret_cast<const uint32_t*>(sp + i0);
+    const uint32_t ca = *reinterpret_cast<const uint32_t*>(sp + P.state_stride + i0);
+    const uint32_t rb = *reinterpret_cast<const uint32_t*>(sp + 2 * P.state_stride + i0);
+    const uint32_t cb = *reinterpret_cast<const uint32_t*>(sp + 3 * P.state_stride + i0);
+    const uint32_t ps = *reinterpret_cast<const uint32_t*>(sp + 4 * P.state_stride + i0);
+    const uint32_t tt = *reinterpret_cast<const uint32_t*>(sp + 5 * P.state_stride + i0);
+    const uint32_t aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
+    const uint32_t ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
+    const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
+    const uint32_t Wm1 = (uint32_t)(P.W - 1);
+    uint32_t A[4], B[4], p[4], fz[4], t[4], a[4], b[4], gA[4], gB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t sh = 8u * j, psj = (ps >> sh) & 0xffu;
+        A[j] = make_pos((ra >> sh) & 0xffu, (ca >> sh) & 0xffu, P.W);
+        B[j] = make_pos((rb >> sh) & 0xffu, (cb >> sh) & 0xffu, P.W);
+        p[j] = psj & 1u; fz[j] = (psj >> 1) & 1u; t[j] = (tt >> sh) & 0xffu;
+        a[j] = (aa >> sh) & 0xffu; b[j] = (ab >> sh) & 0xffu;
+        gA[j] = moved(T, P, A[j], p[j] ^ 1u, a[j]); gB[j] = moved(T, P, B[j], p[j], b[j]);
+    }
+    uint32_t nA[4], nB[4], np[4], nt[4], nd[4], ob[4], tr[4], dn[4]; int32_t rw[4];
+    uint32_t special = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t cc = col_of(p[j] ? B[j] : A[j]);
+        const bool in_goal = (cc == 0u) | (cc == Wm1);
+        const Resolved R = classify(A[j], B[j], gA[j], gB[j], a[j], b[j]);
+        const uint32_t w = blk.w[j], top2 = w >> 30;
+        const uint32_t k = R.kind == K_COIN ? (top2 >> 1) : top2;
+        Outcome sel = pick(A[j], B[j], p[j], R, k);
+        sel.A = in_goal ? A[j] : sel.A; sel.B = in_goal ? B[j] : sel.B; sel.p = in_goal ? p[j] : sel.p;
+        const uint32_t ncc = col_of(sel.p ? sel.B : sel.A);
+        const bool goal_now = (ncc == 0u) | (ncc == Wm1);
+        rw[j] = (goal_now & !in_goal) ? (ncc == Wm1 ? 1 : -1) : 0;
+        nt[j] = t[j] + 1u; tr[j] = nt[j] >= (uint32_t)P.max_steps ? 1u : 0u; dn[j] = goal_now ? 1u : 0u;
+        nd[j] = dn[j] | tr[j];
+        nA[j] = sel.A; nB[j] = sel.B; np[j] = sel.p;
+        ob[j] = obs_of(T, P, sel.A, sel.B, sel.p);
+        special |= (nd[j] & P.autoreset) | fz[j];
+    }
+    bool mis = false;
+    if (special) {
+        uint4 e[4]; uint32_t cur[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] = *reinterpret_cast<const uint4*>(T.isd + 4u * ((blk.w[j] & 3u) >> P.isd_shift));
+            cur[j] = obs_of(T, P, A[j], B[j], p[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool rs = (nd[j] & P.autoreset) != 0u, frozen = fz[j] != 0u;
+            nA[j] = rs ? e[j].x : nA[j]; nB[j] = rs ? e[j].y : nB[j]; np[j] = rs ? (e[j].z & 1u) : np[j];
+            nt[j] = rs ? 0u : nt[j]; ob[j] = rs ? (e[j].z >> 16) : ob[j]; nd[j] = rs ? 0u : nd[j];
+            const uint32_t cc = col_of(p[j] ? B[j] : A[j]);
+            const bool in_goal = (cc == 0u) | (cc == Wm1);
+            nA[j] = frozen ? A[j] : nA[j]; nB[j] = frozen ? B[j] : nB[j]; np[j] = frozen ? p[j] : np[j];
+            tr[j] = frozen ? (t[j] >= (uint32_t)P.max_steps ? 1u : 0u) : tr[j]; dn[j] = frozen ? (in_goal ? 1u : 0u) : dn[j];
+            nt[j] = frozen ? t[j] : nt[j]; nd[j] = frozen ? 1u : nd[j]; ob[j] = frozen ? cur[j] : ob[j]; rw[j] = frozen ? 0 : rw[j];
+            mis |= frozen;
+        }
+    }
+    uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t sh = 8u * j;
+        nra |= (nA[j] >> 24) << sh; nca |= ((nA[j] >> 16) & 0xffu) << sh; nrb |= (nB[j] >> 24) << sh; ncb |= ((nB[j] >> 16) & 0xffu) << sh;
+        nps |= (np[j] | (nd[j] << 1)) << sh; ntt |= nt[j] << sh;
+        o_rew |= ((uint32_t)rw[j] & 0xffu) << sh; o_term |= dn[j] << sh; o_trunc |= tr[j] << sh;
+    }
+    const uint32_t o_lo = ob[0] | (ob[1] << 16), o_hi = ob[2] | (ob[3] << 16);
+    uint8_t* sw = P.state;
+    *reinterpret_cast<uint32_t*>(sw + i0) = nra; *reinterpret_cast<uint32_t*>(sw + P.state_stride + i0) = nca;
+    *reinterpret_cast<uint32_t*>(sw + 2 * P.state_stride + i0) = nrb; *reinterpret_cast<uint32_t*>(sw + 3 * P.state_stride + i0) = ncb;
+    *reinterpret_cast<uint32_t*>(sw + 4 * P.state_stride + i0) = nps; *reinterpret_cast<uint32_t*>(sw + 5 * P.state_stride + i0) = ntt;
+    if (IO.obs) __builtin_nontemporal_store((unsigned long long)o_lo | ((unsigned long long)o_hi << 32), reinterpret_cast<unsigned long long*>(IO.obs + i0));
+    if (IO.reward) __builtin_nontemporal_store(o_rew, reinterpret_cast<uint32_t*>(IO.reward + i0));
+    if (IO.terminated) __builtin_nontemporal_store(o_term, reinterpret_cast<uint32_t*>(IO.terminated + i0));
+    if (IO.truncated) __builtin_nontemporal_store(o_trunc, reinterpret_cast<uint32_t*>(IO.truncated + i0));
+    if (mis) *P.misuse = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_phased(uint8_t* state, unsigned long long stride, const int8_t* act_a, const int8_t* act_b,
+                                                   unsigned long long tick, unsigned long long n, unsigned long long first,
+                                                   const KernelParams P, const StepIO IO) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if ((g << 2) >= n) return;
+    KernelParams Q = P; Q.state = state; Q.state_stride = stride; Q.n = n; Q.first = first;
+    StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
+    hot_group_phased(Q, J, g, tick);
+}
+
 // STRIDE: uint32 words between consecutive workgroups' counters (1 = packed, 16 = one 64-byte line each)
 template <bool SLIP, int STRIDE>
 __global__ __launch_bounds__(kBlock) void k_chain(const KernelParams P, const StepIO IO, unsigned long long tick,
@@ -121,6 +219,10 @@ int main(int argc, char** argv) {
     timed("preload + lane loop unrolled x2", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 2>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
     timed("preload + lane loop unrolled x4", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 4>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload, phased body (gathers grouped, resets patched once)", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL(k_phased, dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
+    printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
+    timed("preload x4 (again)", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_pre<false, 4>), dim3(1024), dim3(256), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
     timed("preload x4, 128-thread workgroups", [&](int k) { StepIO io = io_for(k); hipLaunchKernelGGL((k_plain_blk<false, 128>), dim3(2048), dim3(128), 0, st, P.state, P.state_stride, io.act_a, io.act_b, (unsigned long long)k, P.n, P.first, P, io); }, &got);
     printf("   identical to plain: %s\n", ref == got ? "yes" : "NO");
