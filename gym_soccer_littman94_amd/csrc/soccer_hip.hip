@@ -302,6 +302,7 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     {
         static const int cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
         bool ok = cfg->slip_prob != 0.0 && P.nb >= 1;
+        uint32_t danger[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; int n_danger = 0;
         // Dyadic slips (0.5, 0.25, 0.75, 1.0 ...): every weight is a short binary fraction and every float64 sum
         // of the lists is EXACT, so the nominal thresholds ARE the running sums and the integer comparison is the
         // reference's comparison even when a draw sits exactly on a threshold.  Checked with error-free sums.
@@ -333,8 +334,14 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
             const double x = t * 0x1.0p30;                              // exact
             if (!(x >= 0.0) || x > 0x1.0p31) { ok = false; out = 0xFFFFFFFFu; return; }
             const double r = __builtin_nearbyint(x);
-            // a draw m = r (< 2^30) could sit on / next to the threshold: only safe when the sums are exact
-            if (!exact && __builtin_fabs(x - r) < 0x1.0p-10 && r < 0x1.0p30) ok = false;
+            // a draw m = r (< 2^30) could sit on / next to the threshold: only safe when the sums are exact;
+            // otherwise remember r — a lane that draws it walks the float64 sums (slip_int = 2)
+            if (!exact && __builtin_fabs(x - r) < 0x1.0p-10 && r < 0x1.0p30) {
+                const uint32_t ri = (uint32_t)r;
+                bool seen = false;
+                for (int q = 0; q < n_danger && q < 4; ++q) seen = seen || danger[q] == ri;
+                if (!seen) { if (n_danger < 4) danger[n_danger] = ri; ++n_danger; }
+            }
             out = (uint32_t)__builtin_ceil(x);
         };
         std::vector<uint4> sub(9, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
@@ -349,7 +356,8 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
             scaled(a1, sub[i].x); scaled(b1, sub[i].y); scaled(b2, sub[i].z); scaled(b3, sub[i].w);
         }
         if (ok && P.CB[P.nb - 1] < (1u << 30)) ok = false;             // some draw would fall beyond the last entry
-        P.slip_int = ok ? 1u : 0u;
+        P.slip_int = !ok || n_danger > 4 ? 0u : (n_danger ? 2u : 1u);
+        for (int q = 0; q < 4; ++q) P.danger[q] = danger[q];
         CREATE_TRY(hipMalloc(&h->d_sub, sub.size() * sizeof(uint4)));
         CREATE_TRY(hipMemcpy(h->d_sub, sub.data(), sub.size() * sizeof(uint4), hipMemcpyHostToDevice));
         P.sub = h->d_sub;
@@ -387,7 +395,7 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
     h->grid_cap = prop.multiProcessorCount * 8;
     h->n_cu = prop.multiProcessorCount;
-    if (!h->slip || P.slip_int) {     // LDS transition table for batched_rollout, when it fits (slip: integer decision only)
+    if (!h->slip || P.slip_int == 1u) {     // LDS transition table for batched_rollout, when it fits (slip: integer decision only)
         std::vector<uint32_t> trans, code_tuple; std::vector<uint16_t> code_lut; bool fits = false;
         const std::string terr = build_transition_table(R, trans, code_lut, code_tuple, fits);
         if (!terr.empty()) { free_handle(h); return fail(nullptr, SOCCER_E_INVALID, "%s", terr.c_str()); }
@@ -510,7 +518,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
         const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
         const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
 #define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, P.tick_in, P.n, P.first, P, io
-        if (h->slip && P.slip_int) hipLaunchKernelGGL((step_kernel_hot<true, true, true>), gh, b, 0, h->stream, HOT_ARGS);
+        if (h->slip && P.slip_int == 1u) hipLaunchKernelGGL((step_kernel_hot<true, true, true>), gh, b, 0, h->stream, HOT_ARGS);
         else if (h->slip) hipLaunchKernelGGL((step_kernel_hot<true, false, true>), gh, b, 0, h->stream, HOT_ARGS);
         else hipLaunchKernelGGL((step_kernel_hot<false, false, true>), gh, b, 0, h->stream, HOT_ARGS);
 #undef HOT_ARGS
@@ -525,7 +533,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
             const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
             const dim3 gh(static_cast<unsigned>(blocks));
 #define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, P.tick_in, P.n, P.first, P, io
-            if (h->slip && P.slip_int) hipLaunchKernelGGL((step_kernel_hot<true, true>), gh, b, 0, h->stream, HOT_ARGS);
+            if (h->slip && P.slip_int == 1u) hipLaunchKernelGGL((step_kernel_hot<true, true>), gh, b, 0, h->stream, HOT_ARGS);
             else if (h->slip) hipLaunchKernelGGL(step_kernel_hot<true>, gh, b, 0, h->stream, HOT_ARGS);
             else hipLaunchKernelGGL(step_kernel_hot<false>, gh, b, 0, h->stream, HOT_ARGS);
 #undef HOT_ARGS

@@ -74,7 +74,9 @@ struct KernelParams {
     // (9 combination ends CB, 9 x 4 within-combination thresholds `sub`) lies within 2^-10 of an integer after
     // scaling, i.e. that no such draw can be within 2^-40 of a threshold: then the nominal decision is the exact one
     // and the float64 walk is never needed (slip_int = 1).
-    uint32_t CB[9]; uint32_t slip_int;
+    uint32_t CB[9]; uint32_t slip_int;    // 0 float64 only, 1 integer only, 2 integer except for draws m in `danger`
+    uint32_t danger[4];                   // slip_int == 2: the (at most four) integers m < 2^30 that sit within 2^-10 of a
+                                          // scaled threshold; lanes drawing one of them walk the float64 sums (p = 2^-30)
     const uint4* sub;                     // [9] per active combination: { t1 (2 outcomes), t1, t2, t3 (4 outcomes) }, scaled
 };
 
@@ -278,7 +280,10 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         constexpr uint32_t CL2 = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
         const double w0 = P.w[0], w1 = P.w[1], w2 = P.w[2], w3 = P.w[3];
 #define SOCCER_WEIGHT_OF(cl) (((cl) & 2u) ? (((cl) & 1u) ? w3 : w2) : (((cl) & 1u) ? w1 : w0))
-        if (INT_ONLY || (WORD && P.slip_int)) {                         // uniform
+        bool use_int = INT_ONLY || (WORD && P.slip_int != 0u);           // uniform ...
+        if (!INT_ONLY && WORD && P.slip_int == 2u)                      // ... except for a draw on a dangerous integer
+            use_int = !((d.m == P.danger[0]) | (d.m == P.danger[1]) | (d.m == P.danger[2]) | (d.m == P.danger[3]));
+        if (use_int) {
             // Integer decision (see KernelParams::CB): combination = number of scaled cumulative weights <= m,
             // outcome within it = number of its scaled thresholds <= m.  No float64, no fallback — and the
             // combination is known before the move table is read, so two reads suffice.

@@ -380,6 +380,7 @@ def test_philox_draws_on_slip_thresholds_match_the_float64_cumsum():
             kinds.add(name)
         b.close()
     assert checked > 300 and kinds == {"end", "two", "four1", "four2", "four3"}
+    assert any(h.get("danger") for h in d["hits"])      # slip 0.1: draws exactly on its near-integer threshold (float64 fallback lane)
 
 
 @pytest.mark.parametrize("learner", ["player_a", "player_b"])
@@ -436,8 +437,8 @@ def test_single_agent_rollout_and_step_agree_with_oracle_policy_gather():
     b.close(); b2.close()
 
 
-# slips 0.2 / 0.3 / 0.05 take the integer threshold decision (KernelParams::CB), 0.5 / 0.1 / 0.9 have a scaled
-# threshold on or next to an integer and stay on the float64 two-tier decision
+# slips 0.2 / 0.3 / 0.05 take the integer threshold decision (KernelParams::CB), 0.5 too (dyadic: exact sums); 0.1 and 0.9
+# have one scaled threshold within 2^-10 of an integer: integer decision except for a lane that draws exactly that integer
 @pytest.mark.parametrize("slip,n,off", [(0.0, 65536, 0), (0.0, 65536 + 6, 1 << 33), (0.2, 32768, 4 * 123457), (0.0, 5, 0), (0.2, 3, 8),
                                         (0.3, 16384, 0), (0.05, 16384, 8), (0.5, 16384, 0), (0.1, 8192, 0), (0.9, 8192, 4)])
 def test_hot_instantiation_plain_step_vs_oracle(slip, n, off):

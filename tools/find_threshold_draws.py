@@ -54,7 +54,8 @@ def thresholds(slip):
 def main():
     seed, n_lanes, ticks = 20241004, 1 << 22, 96
     res = {"seed": seed, "hits": []}
-    for slip in (0.2, 0.3, 0.5):   # 0.5: dyadic, every float64 sum exact, thresholds ARE integers after scaling
+    for slip in (0.2, 0.3, 0.5, 0.1):   # 0.5: dyadic, every float64 sum exact, thresholds ARE integers after scaling;
+                                        # 0.1: one scaled threshold within 2^-10 of an integer (searched for specifically below)
         th = thresholds(slip)
         targets = {}
         for name, c, t in th:
@@ -76,6 +77,25 @@ def main():
                                     "thresholds": [list(x) for x in targets[int(m[j, qi])]]})
                 found += 1
         print("slip %.2f: %d draws on/next to a threshold in %d lanes x %d ticks" % (slip, found, n_lanes, ticks), file=sys.stderr)
+        # thresholds whose scaled value is (almost) an integer although the sums are not exact: the kernels send the
+        # lane that draws exactly that integer down the float64 path — find such draws (p = 2^-30 each)
+        danger = {}
+        for name, c, t in th:
+            x = t * 2.0 ** 30; r = round(x)
+            if abs(x - r) < 2.0 ** -10 and r < (1 << 30) and slip not in (0.5,):
+                danger.setdefault(int(r), []).append((name, c))
+        if danger:
+            darr = np.array(sorted(danger), np.uint32); got = 0
+            for tick in range(ticks, ticks + 1400):
+                w = philox_blocks(q, tick, seed); m = w >> 2
+                hit = np.isin(m, darr)
+                for j, qi in zip(*np.nonzero(hit)):
+                    res["hits"].append({"slip": slip, "lane": int(qi) * 4 + int(j), "tick": tick, "m": int(m[j, qi]),
+                                        "thresholds": [list(x) for x in danger[int(m[j, qi])]], "danger": True})
+                    got += 1
+                if got >= 3:
+                    break
+            print("slip %.2f: %d draws exactly on the dangerous integer(s) %s" % (slip, got, sorted(danger)), file=sys.stderr)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "threshold_draws.json")
     with open(out, "w") as f:
         json.dump(res, f, indent=0)
