@@ -168,6 +168,8 @@ def test_mt19937_trajectories_lane_parallel(path):
     (0.3, 7, 5, 4, 8191),
     (1.0, 5, 4, 4, 8192),
     (0.0, 11, 7, 4, 8192),
+    (0.2, 11, 7, 4, 4096),      # integer slip decision on a pitch whose tables do not fit the LDS
+    (0.1, 6, 4, 4, 4100),       # slip with one near-integer threshold (slip_int = 2)
 ])
 def test_config2_autoreset_every_lane_every_step_vs_oracle(slip, width, height, epw, n):
     """BASELINE config 2: 65 536 lanes, Philox seed 0, 200 steps (forces truncation at t=100 and
