@@ -811,6 +811,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     // the thread's 4 lanes are exactly one Philox block; computed while the loads are in flight
     const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
     uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
+    uint32_t posA[4] = {0u, 0u, 0u, 0u}, posB[4] = {0u, 0u, 0u, 0u};   // UNROLL == 4 only
     bool mis = false;
 #pragma unroll UNROLL
     for (int j = 0; j < 4; ++j) {
@@ -829,12 +830,24 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
             if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
         }
         mis |= lane_step<SLIP, true, INT_ONLY>(T, P, L, a_now, b_now, draw_from_word(w), R);
-        nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
-        nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
+        if constexpr (UNROLL == 4) { posA[j] = L.A; posB[j] = L.B; }    // rows / columns gathered with v_perm after the loop
+        else {
+            nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
+            nrb = __builtin_amdgcn_alignbyte(L.B >> 24, nrb, 1); ncb = __builtin_amdgcn_alignbyte((L.B >> 16) & 0xffu, ncb, 1);
+        }
         nps = __builtin_amdgcn_alignbyte(L.p | (L.need << 1), nps, 1); ntt = __builtin_amdgcn_alignbyte(L.t, ntt, 1);
         o_rew = __builtin_amdgcn_alignbyte((uint32_t)R.reward & 0xffu, o_rew, 1);
         o_term = __builtin_amdgcn_alignbyte(R.term, o_term, 1); o_trunc = __builtin_amdgcn_alignbyte(R.trunc, o_trunc, 1);
         o_lo = __builtin_amdgcn_alignbit(o_hi, o_lo, 16); o_hi = (o_hi >> 16) | (R.obs << 16);
+    }
+    if constexpr (UNROLL == 4) {
+        // the row (byte 3) and column (byte 2) of four position words -> the packed row / column dwords: 4 byte
+        // permutes per player instead of a shift + funnel shift per lane and field (v_perm_b32 picks bytes 0-3 from
+        // its second operand, 4-7 from its first)
+        const uint32_t a01 = __builtin_amdgcn_perm(posA[1], posA[0], 0x07030602u), a23 = __builtin_amdgcn_perm(posA[3], posA[2], 0x07030602u);
+        const uint32_t b01 = __builtin_amdgcn_perm(posB[1], posB[0], 0x07030602u), b23 = __builtin_amdgcn_perm(posB[3], posB[2], 0x07030602u);
+        nca = __builtin_amdgcn_perm(a23, a01, 0x05040100u); nra = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+        ncb = __builtin_amdgcn_perm(b23, b01, 0x05040100u); nrb = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
     }
     uint8_t* sw = P.state;
     *reinterpret_cast<uint32_t*>(sw + i0) = nra; *reinterpret_cast<uint32_t*>(sw + P.state_stride + i0) = nca;
