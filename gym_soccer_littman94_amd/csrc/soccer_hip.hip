@@ -517,7 +517,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
     if (policy_only && vec && shared && lean0) {                            // the hot kernel with the policy lookup
         const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
         const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
-#define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, P.tick_in, P.n, P.first, P, io
+#define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), P, io
         if (h->slip && P.slip_int == 1u) hipLaunchKernelGGL((step_kernel_hot<true, true, true>), gh, b, 0, h->stream, HOT_ARGS);
         else if (h->slip) hipLaunchKernelGGL((step_kernel_hot<true, false, true>), gh, b, 0, h->stream, HOT_ARGS);
         else hipLaunchKernelGGL((step_kernel_hot<false, false, true>), gh, b, 0, h->stream, HOT_ARGS);
@@ -532,7 +532,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
         if (lean) {                 // one 4-lane group per thread, as many workgroups as it takes
             const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
             const dim3 gh(static_cast<unsigned>(blocks));
-#define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, P.tick_in, P.n, P.first, P, io
+#define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), P, io
             if (h->slip && P.slip_int == 1u) hipLaunchKernelGGL((step_kernel_hot<true, true>), gh, b, 0, h->stream, HOT_ARGS);
             else if (h->slip) hipLaunchKernelGGL(step_kernel_hot<true>, gh, b, 0, h->stream, HOT_ARGS);
             else hipLaunchKernelGGL(step_kernel_hot<false>, gh, b, 0, h->stream, HOT_ARGS);
