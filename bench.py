@@ -62,6 +62,63 @@ def cpu_baseline(lanes_total, slip, seconds):
                       % (threads, per, counts[0], dt)}
 
 
+REFERENCE_PYTHON = {"value": 5.3e4, "unit": "env-steps/s", "cores": 1, "where": "build container (Xeon 2.1 GHz)",
+                    "what": "the reference's own SoccerSimultaneousEnv.step loop, BASELINE config 1 (slip 0; 4.7e4 at slip 0.2)",
+                    "source": "BASELINE.md section 2 (the reference's Python cannot travel to the GPU box)"}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.
+
+    Runs in a parent process that has NOT touched the GPU (no torch import, no libsoccer_hip load): each rank
+    is a fresh child `python bench.py <same flags>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly
+    what torch.distributed.run would set.  Children inherit stdout, so rank 0's JSON line is the only one.
+    Returns the exit code: 0 only if every rank exited 0; the first failure ends the others."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()          # exactly the children started above
+        time.sleep(0.05)
+    return rc
+
+
+def launcher_selftest(args, rank, world):
+    """CPU-only rehearsal of the multi-rank wiring (tests/test_bench_launcher.py): rendezvous over gloo,
+    one all_reduce, one JSON line from rank 0.  No GPU work and no measurement — never a bench result."""
+    import torch
+    import torch.distributed as dist
+    if args.selftest_fail_rank == rank:
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "rank_sum": float(t[0]),
+                          "env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,12 +134,24 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearse the multi-rank path on fewer GPUs than ranks (ranks share devices, "
                          "collectives go through host tensors); nccl (= RCCL over xGMI) is the real path")
+    ap.add_argument("--no-vector-env", action="store_true", help="skip the VectorSoccerEnv(io='device') timing")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    # ---- rank bring-up: before anything touches the GPU -------------------------------------------
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))         # parent: no torch, no HIP
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; start it as `python bench.py --gpus N` or with "
+                         "torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world)
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to bench)")
     gloo = args.dist_backend == "gloo"
@@ -96,7 +165,6 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gym_soccer_littman94_amd import SoccerBatch
     from gym_soccer_littman94_amd.distributed import gather_lane_values, reduce_histogram, shard_range
@@ -131,7 +199,9 @@ def main():
         b.graph_begin()
         for k in range(KG):
             enqueue(k)
-        graph = b.graph_end()
+        graph = b.graph_end()         # instantiated and uploaded (hipGraphUpload)
+        b.graph_launch(graph, 1)      # one untimed replay: the timed region replays a warm graph (the workload is
+        b.sync()                      # stationary, so advancing the state by KG more steps changes nothing)
     b.reset_stats()
     eager_args = None
     if graph is None:       # eager launches: device addresses resolved before the timed region

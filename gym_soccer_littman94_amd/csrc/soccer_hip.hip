@@ -1292,6 +1292,10 @@ extern "C" int soccer_graph_end(soccer_handle* h, soccer_graph** out) {
         (void)hipGraphDestroy(graph); delete g;
         return fail(h, SOCCER_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
     }
+    // move the executable graph to the device now, so that the first soccer_graph_launch does not pay for it
+    // (best effort: a runtime without hipGraphUpload support just uploads on first launch)
+    (void)hipGraphUpload(g->exec, h->stream);
+    (void)hipGetLastError();
     *out = g;
     return SOCCER_OK;
 }

@@ -25,20 +25,26 @@ def shard_range(global_lanes, rank, world):
 
 def gather_lane_values(local, global_lanes, group=None):
     """all_gather per-lane values (1-D tensor on this rank's device) into global lane order.
-    Shards may differ by one lane, so pad to the largest shard and trim."""
+    Equal shards (BASELINE config 4: 8 x 2^20) go through ONE all_gather_into_tensor into the output
+    buffer; otherwise shards differ by one lane and are padded to the largest one and trimmed."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     base, extra = divmod(int(global_lanes), world)
-    width = base + (1 if extra else 0)
+    if extra == 0:
+        assert local.numel() == base, "this rank's shard has %d lanes, expected %d" % (local.numel(), base)
+        out = torch.empty(base * world, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    width = base + 1
     padded = torch.zeros(width, dtype=local.dtype, device=local.device)
     padded[: local.numel()] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
+    flat = torch.empty(width * world, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(flat, padded, group=group)
     out = []
-    for r, p in enumerate(parts):
+    for r in range(world):
         lo, hi = shard_range(global_lanes, r, world)
-        out.append(p[: hi - lo])
+        out.append(flat[r * width: r * width + hi - lo])
     return torch.cat(out)
 
 

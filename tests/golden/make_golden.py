@@ -26,7 +26,8 @@ What is dumped
   single_5x4_s{slip}_{agent}.npz  single-agent (fixed-opponent) transition table
   vi_5x4_s{slip}_{agent}_vs_{opp}.npz  the reference's value_iteration (utils/planners.py) on its own tables
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py                  (everything below 11x7)
+        python tests/golden/make_golden.py one 11 7 0.0 4000   (one pitch: table + replay + reset)
 """
 import json
 import os
@@ -343,9 +344,22 @@ def main_planners():
             dump_other_planners(env, policy, slip, learner, opp)
 
 
+def main_one(w, h, s, nrep):
+    """One pitch only, e.g. `make_golden.py one 11 7 0.0 4000` — the reference's largest parametrisation
+    (gym_soccer/tests/test_general.py:5-11); its constructor takes ~2 minutes."""
+    _install_gym_stand_in()
+    from gym_soccer.envs import SoccerSimultaneousEnv as Env
+    env = dump_table(Env, w, h, s)
+    dump_replay(env, w, h, s, nrep, seed=1000 + w * 10 + h)
+    if s == 0.0:
+        dump_reset(env, w, h)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "planners":
         main_planners()
+    elif len(sys.argv) > 1 and sys.argv[1] == "one":
+        main_one(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 4000)
     else:
         main()
         main_planners()
