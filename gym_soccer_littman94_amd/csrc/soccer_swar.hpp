@@ -1,0 +1,300 @@
+// soccer_swar.hpp — one step of FOUR environments at once, on the packed SoA dwords as they are loaded.
+//
+// The state streams (row_a, col_a, row_b, col_b, poss, t) and the action streams hold one byte per lane, so the
+// dword a thread loads from each stream carries four consecutive lanes.  Instead of peeling the bytes apart,
+// stepping lane by lane through the rule tables and re-packing the results, everything below works on the four
+// bytes of a dword in parallel (SIMD within a register): byte-wise table lookups by v_perm_b32 with the DATA as
+// the selector, carry-free byte arithmetic (every value is < 128, bit 7 of each byte is the guard), truth values
+// carried in bit 7 of each byte ("flag words": the other 7 bits are don't-care, so AND / OR / BFI / XOR work
+// bitwise), and byte masks made from flag words with the sign-replicating selectors of v_perm_b32.  No rule
+// table is read from memory at all: cell moves, the ordered collision test, the outcome pick, done / reward, the
+// reset from the initial state distribution and the observation index (its closed form, see Rules::build) are
+// arithmetic.  Per env-step this is ~45 vector instructions instead of ~128, and no dependent gather.
+//
+// What is evaluated, and where the reference states it (gym_soccer/envs/soccer_simultaneous_env.py):
+//   cell move .............................. _next_cell          :364-373
+//   ordered 5-way collision resolution ..... _get_next_state     :296-362
+//   slip: the selected combination's moves . :202-227 (the combination is chosen per lane by the caller)
+//   done / reward .......................... :235-240
+//   bookkeeping (timestep, truncation) ..... :396-406
+//   reset from the ISD ..................... :410-424 (:146-165)
+//   observation index ...................... :63-109, :487-497 (closed form of the enumeration order)
+//
+// The same source compiles for the device (builtins) and for the host (plain C++ restatements of the four
+// builtins), so tests/test_swar_host.py checks it on the CPU against the oracle for EVERY tuple x joint action x
+// outcome draw of every golden pitch — no GPU needed to know the rules are right.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SOCCER_HD __host__ __device__ __forceinline__
+#else
+#define SOCCER_HD inline
+#endif
+
+namespace soccer {
+namespace swar {
+
+// ---- the four machine operations the byte-parallel code leans on ----------------------------------------------
+// v_perm_b32: result byte j = byte sel[j] of the 8 bytes {hi: 7..4, lo: 3..0}; sel 8..11 = 0x00/0xff by the sign of
+// byte 1 / 3 / 5 / 7; sel 12 = 0x00; sel >= 13 = 0xff.
+SOCCER_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t in = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (sel >> (8 * j)) & 0xffu;
+        uint32_t b;
+        if (s >= 13u) b = 0xffu;
+        else if (s == 12u) b = 0u;
+        else if (s >= 8u) b = ((in >> (8 * (2 * (s - 8u) + 1) + 7)) & 1u) ? 0xffu : 0u;
+        else b = (uint32_t)(in >> (8 * s)) & 0xffu;
+        r |= b << (8 * j);
+    }
+    return r;
+#endif
+}
+// v_bfi_b32: bits of x where m is set, bits of y elsewhere
+SOCCER_HD uint32_t bfi(uint32_t m, uint32_t x, uint32_t y) { return (m & x) | (~m & y); }
+// v_pk_mad_u16: a * b + c on the two 16-bit halves, wrapping
+SOCCER_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 r = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c);
+    return __builtin_bit_cast(uint32_t, r);
+#else
+    const uint32_t lo = ((a & 0xffffu) * (b & 0xffffu) + (c & 0xffffu)) & 0xffffu;
+    const uint32_t hi = ((a >> 16) * (b >> 16) + (c >> 16)) & 0xffffu;
+    return lo | (hi << 16);
+#endif
+}
+
+constexpr uint32_t K80 = 0x80808080u, K01 = 0x01010101u, K7F = 0x7f7f7f7fu;
+
+// flag word (truth in bit 7 of each byte) -> byte mask 0xff / 0x00: the sign selectors of v_perm_b32 reach the odd
+// bytes of its 8-byte input, so the word goes in once as it is and once shifted up by a byte
+SOCCER_HD uint32_t mask_of(uint32_t flag) { return perm(flag << 8, flag, 0x090b080au); }
+// flag word -> 0x01 / 0x00 per byte
+SOCCER_HD uint32_t one_of(uint32_t flag) { return (flag >> 7) & K01; }
+// bytes < 128: flag = (byte == 0)
+SOCCER_HD uint32_t is_zero(uint32_t x) { return K80 - x; }
+
+// Wave-uniform constants of a handle; built once on the host (make_consts) and passed by value.
+struct Consts {
+    uint32_t Wx2;          // W | W << 16: cell id = row * W + col, two byte pairs at a time
+    uint32_t Hp1x4;        // (H + 1) in every byte
+    uint32_t Wm1x4;        // (W - 1) in every byte: B's goal line (column 0 is A's)
+    uint32_t gr_lo_add;    // (0x80 - goal_lo) in every byte: bit 7 of row + this  <=>  row >= goal_lo   (:60)
+    uint32_t gr_hi_add;    // (0x7f - goal_hi) in every byte: bit 7 of row + this  <=>  row >  goal_hi
+    uint32_t trunc_add;    // (0x80 - max_steps) in every byte: bit 7 of t + this   <=>  t >= max_steps   (:404)
+    uint32_t obs_mul;      // 2 * (NI - 1) in both halves, NI = H * (W - 2) interior cells
+    uint32_t isd_ra, isd_rb, isd_p;   // byte k = row of A / row of B / possession of ISD entry k (:146-165)
+    uint32_t isd_ca4, isd_cb4;        // the entries' columns (2 and W - 3) in every byte
+    uint32_t isd_shift, isd_mask;     // entry index = (two random bits >> shift), 4 or 2 entries
+    uint32_t autoreset;
+};
+
+// A pitch qualifies when every byte quantity stays below 128 (bit 7 is the guard bit):
+// cell ids (H * W), 2 * NI + 2 (the observation's low term) and max_steps.
+inline bool fits(int H, int W, int max_steps) {
+    const int NI = H * (W - 2);
+    return H >= 4 && W >= 7 && H * W <= 128 && 2 * NI + 2 <= 255 && max_steps >= 1 && max_steps <= 127;
+}
+
+inline Consts make_consts(int H, int W, int goal_lo, int goal_hi, int max_steps, int n_isd, const int8_t (*isd)[5],
+                          bool autoreset) {
+    Consts C{};
+    auto splat = [](uint32_t b) { return (b & 0xffu) * K01; };
+    C.Wx2 = (uint32_t)W | ((uint32_t)W << 16);
+    C.Hp1x4 = splat((uint32_t)H + 1u);
+    C.Wm1x4 = splat((uint32_t)W - 1u);
+    C.gr_lo_add = splat(0x80u - (uint32_t)goal_lo);
+    C.gr_hi_add = splat(0x7fu - (uint32_t)goal_hi);
+    C.trunc_add = splat(0x80u - (uint32_t)max_steps);
+    const uint32_t m = 2u * (uint32_t)(H * (W - 2) - 1);
+    C.obs_mul = m | (m << 16);
+    for (int k = 0; k < 4; ++k) {
+        const int e = k < n_isd ? k : 0;
+        C.isd_ra |= (uint32_t)(uint8_t)isd[e][0] << (8 * k);
+        C.isd_rb |= (uint32_t)(uint8_t)isd[e][2] << (8 * k);
+        C.isd_p |= (uint32_t)(uint8_t)isd[e][4] << (8 * k);
+    }
+    C.isd_ca4 = splat((uint32_t)(uint8_t)isd[0][1]);
+    C.isd_cb4 = splat((uint32_t)(uint8_t)isd[0][3]);
+    C.isd_shift = n_isd == 4 ? 0u : 1u;
+    C.isd_mask = n_isd == 4 ? 0x03030303u : K01;
+    C.autoreset = autoreset ? 1u : 0u;
+    return C;
+}
+
+// four lanes of the six state streams
+struct Group { uint32_t ra, ca, rb, cb, ps, tt; };
+
+struct Out {
+    uint32_t obs_lo, obs_hi;       // observation after any auto-reset: lanes 0,1 / 2,3 as uint16 pairs
+    uint32_t fin_lo, fin_hi;       // FULL: observation before the reset (gym's final_observation)
+    uint32_t rew, term, trunc;     // bytes
+    uint32_t code;                 // FULL: prob_code = slip class * 3 + outcome class
+    uint32_t finished;             // flag word: the lane's episode ended at this step
+    uint32_t frozen;               // flag word: lanes that needed a reset and were left untouched (:376)
+    uint32_t bad_action;           // non-zero: some action byte was outside 0..4
+};
+
+// byte-wise lookup of an action in an 8-entry table (entries 0..3 in `lo`, 4..7 in `hi`)
+SOCCER_HD uint32_t lut8(uint32_t hi, uint32_t lo, uint32_t a) { return perm(hi, lo, a); }
+
+// the action tables: entry = action 0 NOOP, 1 NORTH, 2 SOUTH, 3 EAST, 4 WEST (:8-31); 5..7 behave as NOOP
+constexpr uint32_t T_DR1_LO = 0x01020001u, T_DR1_HI = 0x01010101u;   // row delta + 1
+constexpr uint32_t T_E_LO = 0x01000000u, T_E_HI = 0u;                  // 1 for EAST
+constexpr uint32_t T_W_LO = 0u, T_W_HI = 0x00000001u;                  // 1 for WEST
+constexpr uint32_t T_NZ_LO = 0x80808000u, T_NZ_HI = 0x00000080u;       // flag: the action is not NOOP
+// an action byte as the kernels execute it: table[byte & 7] with 5..7 -> NOOP, so no byte value can index outside a
+// rule table; canon4(x) != x exactly when some byte of x is outside 0..4 (the reference raises IndexError, :393)
+constexpr uint32_t T_CANON_LO = 0x03020100u, T_CANON_HI = 0x00000004u;
+SOCCER_HD uint32_t canon4(uint32_t x) { return perm(T_CANON_HI, T_CANON_LO, x & 0x07070707u); }
+// slipped move of an action (:205-206): NOOP->NOOP,NOOP NORTH->EAST,WEST SOUTH->WEST,EAST EAST->SOUTH,NORTH WEST->NORTH,SOUTH
+constexpr uint32_t T_SLIP1_LO = 0x02040300u, T_SLIP1_HI = 0x00000001u;
+constexpr uint32_t T_SLIP2_LO = 0x01030400u, T_SLIP2_HI = 0x00000002u;
+
+// one player's tentative cell (_next_cell :364-373) for four lanes: rows clamped to the pitch, a step into a goal
+// column reverted unless the player holds the ball and stands in a goal row.  `mv` = the (possibly slipped) move,
+// `score` = flag word "holds the ball and is in a goal row" (an EAST / WEST move never changes the row).
+SOCCER_HD void move4(const Consts& C, uint32_t r, uint32_t c, uint32_t mv, uint32_t score, uint32_t& nr, uint32_t& nc) {
+    const uint32_t u = r + lut8(T_DR1_HI, T_DR1_LO, mv);                   // row + 1 + drow, in 0 .. H + 1
+    const uint32_t at_top = one_of(is_zero(u));                            // stepped north off row 0
+    const uint32_t at_bot = one_of(is_zero(u ^ C.Hp1x4));                  // stepped south off row H - 1
+    nr = u + at_top + 0xFEFEFEFFu - at_bot;                                // clamp (:365); (u + at_top) >= 1 in every byte
+    const uint32_t ct = c + lut8(T_E_HI, T_E_LO, mv) - lut8(T_W_HI, T_W_LO, mv);   // :366
+    const uint32_t edge = is_zero(ct) | is_zero(ct ^ C.Wm1x4);            // the target is a goal column (:369)
+    const uint32_t revert = bfi(score, 0u, edge);                          // ... and this is not a score (:370-372)
+    nc = bfi(mask_of(revert), c, ct);
+}
+
+// Observation index of four tuples (ra, ca, rb, cb, p): 1 + 2 * (iA * (NI - 1) + iB - (iB > iA)) + p over interior-cell
+// indices i = row * (W - 2) + col - 1 = cell - 2 * row - 1 (Rules::build checks the table against this closed form of
+// the reference's enumeration order, :63-109), evaluated as iA * 2(NI - 1) + (2 * (iB - gt) + 1 + p) on two 16-bit
+// halves at a time.  ZERO: lanes flagged in `zero7` (goal tuples, :493-494) get index 0.
+template <bool ZERO>
+SOCCER_HD void obs4(const Consts& C, uint32_t r_a, uint32_t c_a, uint32_t r_b, uint32_t c_b, uint32_t p01, uint32_t zero7,
+                    uint32_t& lo, uint32_t& hi) {
+    const uint32_t cA = pk_mad(r_a, C.Wx2, c_a), cB = pk_mad(r_b, C.Wx2, c_b);
+    const uint32_t gt = one_of((cB | K80) - cA);                           // cell ids order like interior indices
+    const uint32_t iA = cA - (r_a << 1) - K01;
+    const uint32_t iB = cB - (r_b << 1) - K01 - gt;
+    const uint32_t q = (iB << 1) + p01 + K01;
+    lo = pk_mad(perm(0u, iA, 0x0c010c00u), C.obs_mul, perm(0u, q, 0x0c010c00u));
+    hi = pk_mad(perm(0u, iA, 0x0c030c02u), C.obs_mul, perm(0u, q, 0x0c030c02u));
+    if (ZERO) {
+        const uint32_t z = mask_of(zero7);
+        lo = bfi(perm(0u, z, 0x01010000u), 0u, lo); hi = bfi(perm(0u, z, 0x03030202u), 0u, hi);
+    }
+}
+
+// GENERAL = false: the steady state of an auto-resetting handle — no lane is frozen or stands in a goal tuple on
+//   entry (so none ever will): the code for those cases is compiled out.  The host tracks when that holds.
+// FULL: also produce final_obs and prob_code (VectorSoccerEnv's info / final_observation).
+// SLIP: `sa` / `sb` are the slipped moves of the combination the caller selected per lane and `k4` (bytes 0..3) the
+//   outcome index within it; otherwise the moves are the actions and the outcome index comes from the top two bits of
+//   each lane's random word (slip_prob == 0: list probabilities are 1, .5/.5 or .25 x 4).
+// w0..w3: the lanes' random words (u = (w >> 2) * 2^-30, reset draw = w & 3).
+template <bool GENERAL, bool FULL, bool SLIP>
+SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw, uint32_t sa, uint32_t sb, uint32_t k4,
+                     uint32_t cls4, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, Out& o) {
+    const uint32_t ra = S.ra, ca = S.ca, rb = S.rb, cb = S.cb, ps = S.ps, t = S.tt;
+    // ---- actions: the low three bits select the move, 5..7 are NOOP; any byte outside 0..4 is reported ---------------
+    uint32_t aa = canon4(aa_raw), ab = canon4(ab_raw);
+    o.bad_action = (aa ^ aa_raw) | (ab ^ ab_raw);
+    const uint32_t p7 = ps << 7;                                           // flag: B has the ball
+    const uint32_t pm = mask_of(p7);
+    uint32_t frz7 = 0u, hold_m = 0u, frz_m = 0u;
+    if (GENERAL) {
+        // lanes that are left as they are: frozen (needs_reset, :376) or in a goal tuple (absorbing, :300-301)
+        frz7 = ps << 6;
+        const uint32_t cc0 = bfi(pm, cb, ca);                              // the carrier's column
+        const uint32_t hold7 = frz7 | is_zero(cc0) | is_zero(cc0 ^ C.Wm1x4);
+        hold_m = mask_of(hold7); frz_m = mask_of(frz7);
+        aa = bfi(hold_m, 0u, aa); ab = bfi(hold_m, 0u, ab);                // NOOP / NOOP leaves the tuple unchanged
+        if (SLIP) { sa = bfi(hold_m, 0u, sa); sb = bfi(hold_m, 0u, sb); }
+    }
+    if (!SLIP) { sa = aa; sb = ab; } else { sa &= 0x07070707u; sb &= 0x07070707u; }
+    // ---- tentative cells (:307-312) ---------------------------------------------------------------------------------
+    const uint32_t gra = bfi(ra + C.gr_hi_add, 0u, ra + C.gr_lo_add);     // flag: row in the goal rows
+    const uint32_t grb = bfi(rb + C.gr_hi_add, 0u, rb + C.gr_lo_add);
+    uint32_t nra, nca, nrb, ncb;
+    move4(C, ra, ca, sa, bfi(p7, 0u, gra), nra, nca);                      // A holds the ball when p == 0
+    move4(C, rb, cb, sb, grb & p7, nrb, ncb);
+    // ---- ordered collision resolution (:315-360) on cell ids ---------------------------------------------------------
+    const uint32_t A = pk_mad(ra, C.Wx2, ca), B = pk_mad(rb, C.Wx2, cb);
+    const uint32_t nA = pk_mad(nra, C.Wx2, nca), nB = pk_mad(nrb, C.Wx2, ncb);
+    const uint32_t e1 = is_zero(nA ^ B), e2 = is_zero(nB ^ A);
+    const uint32_t sA = is_zero(nA ^ A), sB = is_zero(nB ^ B), same = is_zero(nA ^ nB);
+    const uint32_t nzA = lut8(T_NZ_HI, T_NZ_LO, aa), nzB = lut8(T_NZ_HI, T_NZ_LO, ab);   // the ORIGINAL actions (:330-339)
+    const uint32_t swap = e1 & e2;                                         // :315-322
+    const uint32_t stander = bfi(nzB, 0u, e1) | bfi(nzA, 0u, e2);          // :330-331
+    const uint32_t bounce = ((sA & nzA) & e2) | ((sB & nzB) & e1);         // :338-339
+    const uint32_t coin = swap | bfi(stander, 0u, bounce);                 // two outcomes .5/.5 (:326-327, :343-344)
+    const uint32_t flip = bfi(coin, 0u, stander);                          // possession changes hands (:335)
+    const uint32_t cs = coin | stander;
+    const uint32_t four = bfi(cs, 0u, same);                               // four outcomes .25 each (:352-356)
+    const uint32_t mv = ~(cs | same);                                      // both move (:360)
+    // ---- the outcome draw ---------------------------------------------------------------------------------------------
+    // kb1 / kb0: flag words of bit 1 / bit 0 of the outcome index k (coin lists use k = bit 1 of the two-bit draw)
+    uint32_t kb1, kb0c, kb0f;                                              // kb0 for coin lists / for four-way lists
+    if (!SLIP) {
+        const uint32_t x01 = perm(w1, w0, 0x0c0c0703u), x23 = perm(w3, w2, 0x0c0c0703u);
+        const uint32_t T4 = perm(x23, x01, 0x05040100u);                   // byte j = top byte of lane j's word
+        kb1 = T4; kb0c = T4; kb0f = T4 << 1;                               // floor(2u) / floor(4u): bits 31 and 30
+    } else {
+        kb1 = k4 << 6; kb0c = k4 << 7; kb0f = kb0c;                        // k in 0..1 (coin) or 0..3 (four)
+    }
+    const uint32_t amv = (four & kb1) | mv;                                // A takes its cell: k >= 2 of a four-way tie
+    const uint32_t bmv = bfi(kb1, mv, four | mv);                          // B takes its cell: k < 2
+    const uint32_t am = mask_of(amv), bm = mask_of(bmv);
+    uint32_t fra = bfi(am, nra, ra), fca = bfi(am, nca, ca), frb = bfi(bm, nrb, rb), fcb = bfi(bm, ncb, cb);
+    const uint32_t p7n = bfi(coin | four, bfi(coin, kb0c, kb0f), p7 ^ flip);
+    // ---- done / reward (:235-240), bookkeeping (:399-406) -------------------------------------------------------------
+    const uint32_t pmn = mask_of(p7n);
+    const uint32_t cc = bfi(pmn, fcb, fca);                                // the carrier's column after the step
+    const uint32_t g0 = is_zero(cc), gW = is_zero(cc ^ C.Wm1x4);
+    const uint32_t goal7 = g0 | gW;
+    uint32_t rew = one_of(gW) | mask_of(g0);                               // +1 into B's goal line, -1 (0xff) into A's
+    if (GENERAL) rew = bfi(hold_m, 0u, rew);                               // from a goal tuple: reward 0 (:235-236)
+    uint32_t tt = t + (GENERAL ? bfi(frz_m, 0u, K01) : K01);               // :399 (a frozen lane keeps its timestep)
+    const uint32_t trunc7 = tt + C.trunc_add;                              // :404
+    const uint32_t need7 = goal7 | trunc7;                                 // :406
+    const uint32_t fin7 = GENERAL ? bfi(frz7, 0u, need7) : need7;          // episodes that ended at this step
+    o.rew = rew; o.term = one_of(goal7); o.trunc = one_of(trunc7);
+    o.finished = fin7; o.frozen = frz7 & K80;
+    if (FULL) {
+        // outcome class of the sampled entry: 0 single, 1 one of two, 2 one of four; slip class from the caller
+        uint32_t code = one_of(coin) | ((four >> 6) & 0x02020202u);
+        if (SLIP) code += cls4 + (cls4 << 1);
+        if (GENERAL && SLIP) code = bfi(frz_m, 0u, code);
+        o.code = code;
+    }
+    uint32_t p01 = one_of(p7n);
+    if (FULL) obs4<true>(C, fra, fca, frb, fcb, p01, goal7, o.fin_lo, o.fin_hi);      // before any reset (goal tuples -> 0)
+    // ---- in-step reset (:410-424): lanes whose episode ended draw an ISD entry with their two low random bits --------
+    uint32_t need_out7 = GENERAL ? (need7 | frz7) : need7;
+    uint32_t obs_zero7 = goal7;
+    if (!GENERAL || C.autoreset) {                                         // wave-uniform
+        const uint32_t rm = mask_of(fin7);
+        const uint32_t y01 = perm(w1, w0, 0x0c0c0400u), y23 = perm(w3, w2, 0x0c0c0400u);
+        const uint32_t idx = (perm(y23, y01, 0x05040100u) >> C.isd_shift) & C.isd_mask;
+        fra = bfi(rm, perm(0u, C.isd_ra, idx), fra); fca = bfi(rm, C.isd_ca4, fca);
+        frb = bfi(rm, perm(0u, C.isd_rb, idx), frb); fcb = bfi(rm, C.isd_cb4, fcb);
+        p01 = bfi(rm, perm(0u, C.isd_p, idx), p01);
+        tt = bfi(rm, 0u, tt);
+        need_out7 = frz7;
+        obs_zero7 = bfi(fin7, 0u, goal7);                                  // only a frozen lane can still sit in a goal tuple
+    }
+    // the observation of the tuple the lane now holds; without frozen lanes no tuple is a goal tuple after the reset
+    obs4<GENERAL>(C, fra, fca, frb, fcb, p01, obs_zero7, o.obs_lo, o.obs_hi);
+    S.ra = fra; S.ca = fca; S.rb = frb; S.cb = fcb; S.tt = tt;
+    S.ps = p01 | ((need_out7 >> 6) & 0x02020202u);
+}
+
+}  // namespace swar
+}  // namespace soccer

@@ -1,0 +1,54 @@
+// Host build of the product's byte-parallel step (gym_soccer_littman94_amd/csrc/soccer_swar.hpp) for the CPU test
+// tests/test_swar_host.py: the four GPU builtins it uses are restated in plain C++ inside that header, everything
+// else is the code the kernels run.  Test infrastructure; not part of libsoccer_hip.so.
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../gym_soccer_littman94_amd/csrc/soccer_rules.hpp"
+#include "../../gym_soccer_littman94_amd/csrc/soccer_swar.hpp"
+
+using namespace soccer;
+
+static uint32_t ld4(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+static void st4(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
+
+// n must be a multiple of 4.  state: six byte streams of n lanes (in / out).  words: one uint32 per lane.
+// slip arrays (nullable together): sa, sb = slipped moves, k = outcome index, cls = slip class per lane.
+// Returns 0, or -1 when the pitch does not qualify for the byte-parallel path.
+extern "C" int swar_step_host(int width, int height, int max_steps, int autoreset, int general, int full, long n,
+                              uint8_t* ra, uint8_t* ca, uint8_t* rb, uint8_t* cb, uint8_t* ps, uint8_t* tt,
+                              const uint8_t* act_a, const uint8_t* act_b, const uint32_t* words,
+                              const uint8_t* sa, const uint8_t* sb, const uint8_t* k, const uint8_t* cls,
+                              uint16_t* obs, uint16_t* final_obs, uint8_t* rew, uint8_t* term, uint8_t* trunc,
+                              uint8_t* code, uint8_t* finished, uint8_t* frozen, uint8_t* bad) {
+    Rules R;
+    if (!R.build(width, height).empty()) return -2;
+    if (!swar::fits(R.H, R.W, max_steps)) return -1;
+    const swar::Consts C = swar::make_consts(R.H, R.W, R.goal_lo, R.goal_hi, max_steps, R.n_isd, R.isd, autoreset != 0);
+    for (long i = 0; i < n; i += 4) {
+        swar::Group S{ld4(ra + i), ld4(ca + i), ld4(rb + i), ld4(cb + i), ld4(ps + i), ld4(tt + i)};
+        swar::Out o{};
+        const uint32_t a = ld4(act_a + i), b = ld4(act_b + i);
+        const uint32_t* w = words + i;
+        const bool slip = sa != nullptr;
+        const uint32_t s_a = slip ? ld4(sa + i) : 0u, s_b = slip ? ld4(sb + i) : 0u, k4 = slip ? ld4(k + i) : 0u, c4 = slip ? ld4(cls + i) : 0u;
+#define CALL(G, F, SL) swar::step4<G, F, SL>(C, S, a, b, s_a, s_b, k4, c4, w[0], w[1], w[2], w[3], o)
+        if (slip) { if (general) { if (full) CALL(true, true, true); else CALL(true, false, true); }
+                    else { if (full) CALL(false, true, true); else CALL(false, false, true); } }
+        else { if (general) { if (full) CALL(true, true, false); else CALL(true, false, false); }
+               else { if (full) CALL(false, true, false); else CALL(false, false, false); } }
+#undef CALL
+        st4(ra + i, S.ra); st4(ca + i, S.ca); st4(rb + i, S.rb); st4(cb + i, S.cb); st4(ps + i, S.ps); st4(tt + i, S.tt);
+        obs[i] = (uint16_t)o.obs_lo; obs[i + 1] = (uint16_t)(o.obs_lo >> 16); obs[i + 2] = (uint16_t)o.obs_hi; obs[i + 3] = (uint16_t)(o.obs_hi >> 16);
+        if (full) {
+            final_obs[i] = (uint16_t)o.fin_lo; final_obs[i + 1] = (uint16_t)(o.fin_lo >> 16);
+            final_obs[i + 2] = (uint16_t)o.fin_hi; final_obs[i + 3] = (uint16_t)(o.fin_hi >> 16);
+            st4(code + i, o.code);
+        }
+        st4(rew + i, o.rew); st4(term + i, o.term); st4(trunc + i, o.trunc);
+        st4(finished + i, (o.finished >> 7) & 0x01010101u); st4(frozen + i, (o.frozen >> 7) & 0x01010101u);
+        bad[i >> 2] = o.bad_action != 0u;
+    }
+    return 0;
+}

@@ -1,0 +1,175 @@
+"""The byte-parallel step of the hot kernels (csrc/soccer_swar.hpp: four lanes per dword, no rule tables) against the
+oracle, on the CPU, EXHAUSTIVELY: every reachable tuple (live and goal) x 25 joint actions x 4 outcome draws x 4 reset
+draws, at timesteps around the truncation, frozen and not, with and without auto-reset, on every pitch the reference
+parametrises (tests/test_general.py:5-11) — 5x4 ... 11x7.  The header compiles for the host with the four GPU builtins
+it uses restated in C++ (tests/host/swar_host.cpp), so this is the code the kernels run.  The oracle itself is pinned
+to the reference by tests/test_oracle_golden.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("swar") / "libswar_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", "-o", so,
+                           os.path.join(ROOT, "tests", "host", "swar_host.cpp")])
+    L = C.CDLL(so)
+    L.swar_step_host.restype = C.c_int
+    L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 22
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _tuples(o, kinds):
+    lut, kind, gv, isd, isdp = o.tables()
+    f = np.flatnonzero(np.isin(kind, kinds))
+    p = f & 1; r = f >> 1
+    cb = r % o.W; r //= o.W; rb = r % o.H; r //= o.H; ca = r % o.W; ra = r // o.W
+    return np.stack([ra, ca, rb, cb, p], 1).astype(np.int64)
+
+
+def _run_swar(L, w, h, max_steps, autoreset, general, full, st, t, need, aa, ab, words, slip=None):
+    n = len(t)
+    ra, ca, rb, cb = (np.ascontiguousarray(st[:, k], np.uint8) for k in range(4))
+    ps = np.ascontiguousarray(st[:, 4] | (need << 1), np.uint8)
+    tt = np.ascontiguousarray(t, np.uint8)
+    out = dict(obs=np.zeros(n, np.uint16), final_obs=np.zeros(n, np.uint16), reward=np.zeros(n, np.uint8),
+               terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), prob_code=np.zeros(n, np.uint8),
+               finished=np.zeros(n, np.uint8), frozen=np.zeros(n, np.uint8), bad=np.zeros(n // 4, np.uint8))
+    sl = [None] * 4 if slip is None else [np.ascontiguousarray(x, np.uint8) for x in slip]
+    rc = L.swar_step_host(w, h, max_steps, int(autoreset), int(general), int(full), n,
+                          _p(ra), _p(ca), _p(rb), _p(cb), _p(ps), _p(tt),
+                          _p(np.ascontiguousarray(aa, np.uint8)), _p(np.ascontiguousarray(ab, np.uint8)),
+                          _p(np.ascontiguousarray(words, np.uint32)), _p(sl[0]), _p(sl[1]), _p(sl[2]), _p(sl[3]),
+                          _p(out["obs"]), _p(out["final_obs"]), _p(out["reward"]), _p(out["terminated"]),
+                          _p(out["truncated"]), _p(out["prob_code"]), _p(out["finished"]), _p(out["frozen"]), _p(out["bad"]))
+    assert rc == 0
+    out["reward"] = out["reward"].view(np.int8)
+    out["state"] = (ra, ca, rb, cb, ps, tt)
+    return out
+
+
+def _grid(tup, t_values, need_values, rng):
+    """every tuple x 25 joint actions x 4 outcome draws x 4 reset draws, timestep / frozen flag cycled"""
+    nt = len(tup)
+    idx = np.arange(nt * 25 * 16)
+    ti = idx // 400; r = idx % 400
+    aa = r // 80; r %= 80
+    ab = r // 16; r %= 16
+    top2 = r // 4; reset2 = r % 4
+    n = len(idx)
+    pad = (-n) % 4
+    if pad:
+        ti = np.concatenate([ti, ti[:pad]]); aa = np.concatenate([aa, aa[:pad]]); ab = np.concatenate([ab, ab[:pad]])
+        top2 = np.concatenate([top2, top2[:pad]]); reset2 = np.concatenate([reset2, reset2[:pad]])
+        n += pad
+    mid = rng.integers(0, 1 << 28, size=n, dtype=np.uint32)
+    words = (top2.astype(np.uint32) << 30) | (mid << 2) | reset2.astype(np.uint32)
+    t = np.asarray(t_values)[rng.integers(0, len(t_values), size=n)]
+    need = np.asarray(need_values)[rng.integers(0, len(need_values), size=n)]
+    return tup[ti], t, need.astype(np.int64), aa, ab, words
+
+
+def _oracle_step(w, h, max_steps, autoreset, st, t, need, aa, ab, words):
+    n = len(t)
+    o = Oracle(w, h, 0.0, n=n, autoreset=autoreset, max_steps=max_steps)
+    o.set_state(st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], t=t, needs_reset=need)
+    c = o.step(aa, ab, u_step=(words >> 2).astype(np.float64) * 2.0 ** -30, u_reset=(words & 3).astype(np.float64) * 0.25)
+    c["state"] = (o.row_a.view(np.uint8), o.col_a.view(np.uint8), o.row_b.view(np.uint8), o.col_b.view(np.uint8), o.poss, o.t)
+    return c
+
+
+def _compare(got, exp, need, full):
+    for k in ("obs", "reward", "terminated", "truncated") + (("final_obs", "prob_code") if full else ()):
+        bad = np.flatnonzero(got[k] != exp[k])
+        assert bad.size == 0, "%s differs on %d lanes, first %d: got %s expected %s" % (k, bad.size, bad[0], got[k][bad[0]], exp[k][bad[0]])
+    for k, name in enumerate(("row_a", "col_a", "row_b", "col_b", "poss|needs_reset<<1", "t")):
+        bad = np.flatnonzero(got["state"][k] != exp["state"][k])
+        assert bad.size == 0, "state %s differs on %d lanes, first %d" % (name, bad.size, bad[0])
+    fin = ((exp["terminated"] | exp["truncated"]) != 0) & (need == 0)
+    np.testing.assert_array_equal(got["finished"], fin.astype(np.uint8))
+    np.testing.assert_array_equal(got["frozen"], need.astype(np.uint8))
+    assert not got["bad"].any()
+
+
+PITCHES = [(5, 4), (6, 4), (7, 5), (9, 6), (11, 7)]
+
+
+@pytest.mark.parametrize("w,h", PITCHES)
+@pytest.mark.parametrize("autoreset", [True, False])
+def test_general_step_every_tuple_action_and_draw(host, w, h, autoreset):
+    rng = np.random.default_rng(w * 100 + h)
+    o = Oracle(w, h, 0.0, n=1)
+    tup = _tuples(o, [1, 2])                                   # live and goal tuples
+    st, t, need, aa, ab, words = _grid(tup, [0, 1, 57, 98, 99, 100], [0, 0, 0, 1], rng)
+    t = np.where(need == 1, t, np.minimum(t, 99))              # a lane that is not frozen has t < max_steps
+    got = _run_swar(host, w, h, 100, autoreset, True, True, st, t, need, aa, ab, words)
+    exp = _oracle_step(w, h, 100, autoreset, st, t, need, aa, ab, words)
+    _compare(got, exp, need, True)
+    lean = _run_swar(host, w, h, 100, autoreset, True, False, st, t, need, aa, ab, words)
+    _compare(lean, exp, need, False)
+
+
+@pytest.mark.parametrize("w,h", PITCHES)
+def test_steady_state_step_every_live_tuple_action_and_draw(host, w, h):
+    """the instantiation of an auto-resetting handle whose lanes have all been reset: no frozen / goal-tuple code"""
+    rng = np.random.default_rng(w * 100 + h + 1)
+    o = Oracle(w, h, 0.0, n=1)
+    tup = _tuples(o, [1])
+    st, t, need, aa, ab, words = _grid(tup, [0, 3, 98, 99], [0], rng)
+    exp = _oracle_step(w, h, 100, True, st, t, need, aa, ab, words)
+    for full in (True, False):
+        got = _run_swar(host, w, h, 100, True, False, full, st, t, need, aa, ab, words)
+        _compare(got, exp, need, full)
+
+
+def test_other_episode_lengths(host):
+    rng = np.random.default_rng(5)
+    o = Oracle(5, 4, 0.0, n=1)
+    tup = _tuples(o, [1, 2])
+    for ms in (1, 2, 17, 127):
+        st, t, need, aa, ab, words = _grid(tup, [0, max(ms - 2, 0), ms - 1, ms], [0, 0, 1], rng)
+        t = np.where(need == 1, t, np.minimum(t, ms - 1))
+        got = _run_swar(host, 5, 4, ms, True, True, True, st, t, need, aa, ab, words)
+        exp = _oracle_step(5, 4, ms, True, st, t, need, aa, ab, words)
+        _compare(got, exp, need, True)
+
+
+def test_actions_outside_0_4_are_reported_and_never_leave_the_pitch(host):
+    rng = np.random.default_rng(9)
+    o = Oracle(5, 4, 0.0, n=1)
+    tup = _tuples(o, [1])
+    n = 4 * 20000
+    st = tup[rng.integers(0, len(tup), size=n)]
+    aa = rng.integers(0, 5, size=n).astype(np.uint8); ab = rng.integers(0, 5, size=n).astype(np.uint8)
+    bad_lane = np.arange(0, n, 8) + rng.integers(0, 8, size=n // 8)           # one per two groups
+    aa_bad = aa.copy(); ab_bad = ab.copy()
+    vals = np.array([5, 6, 7, 8, 127, 128, 255, 0x85], np.uint8)
+    which = rng.integers(0, 2, size=len(bad_lane)).astype(bool)
+    aa_bad[bad_lane[which]] = vals[rng.integers(0, len(vals), size=which.sum())]
+    ab_bad[bad_lane[~which]] = vals[rng.integers(0, len(vals), size=(~which).sum())]
+    words = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    t = rng.integers(0, 99, size=n); need = np.zeros(n, np.int64)
+    got = _run_swar(host, 5, 4, 100, True, True, False, st, t, need, aa_bad, ab_bad, words)
+    flagged = np.zeros(n // 4, bool); flagged[bad_lane // 4] = True
+    np.testing.assert_array_equal(got["bad"].astype(bool), flagged)
+    # every lane still holds a reachable tuple, and the lanes of clean groups stepped exactly as the oracle does
+    lut, kind, *_ = o.tables()
+    ra, ca, rb, cb, ps, tt = (x.astype(np.int64) for x in got["state"])
+    assert (ra < 4).all() and (rb < 4).all() and (ca < 7).all() and (cb < 7).all()
+    assert (kind[(((ra * 7 + ca) * 4 + rb) * 7 + cb) * 2 + (ps & 1)] == 1).all()      # auto-reset on: live tuples only
+    exp = _oracle_step(5, 4, 100, True, st, t, need, aa, ab, words)
+    clean = np.repeat(~flagged, 4)
+    for k in ("obs", "reward", "terminated", "truncated"):
+        np.testing.assert_array_equal(got[k][clean], exp[k][clean])
