@@ -67,6 +67,17 @@ REFERENCE_PYTHON = {"value": 5.3e4, "unit": "env-steps/s", "cores": 1, "where": 
                     "source": "BASELINE.md section 2 (the reference's Python cannot travel to the GPU box)"}
 
 
+def csrc_sha256():
+    """Fingerprint of the kernel sources: profiles/traffic.json records the one its PMC run was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gym_soccer_littman94_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", "Makefile")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.
 
@@ -306,16 +317,50 @@ def main():
         selfplay = {"horizon": T, "env_steps_per_s": world * N * T / (s_ms * 1e-3),
                     "return_hist_minus1_0_plus1_over_3_rollouts": [int(x) for x in hsum]}
 
+    # ---- optional: the gym-style surface north_star names, VectorSoccerEnv(io="device").step() -------------------------
+    # one Python call per step = one ctypes call = one launch of the FULL kernel (final_obs + prob_code + episode
+    # histogram on top of the four result streams: 22 B per env-step); eager launches, wall clock around K steps
+    vec_env = None
+    if not args.no_vector_env and world == 1:
+        from gym_soccer_littman94_amd import VectorSoccerEnv
+        with torch.cuda.device(dev):
+            v = VectorSoccerEnv(N, slip_prob=args.slip, seed=0, io="device", device=dev_index)
+            v.reset()
+            KV = max(200, min(K, 1000))
+            pairs = [{"player_a": acts[k % KA, 0], "player_b": acts[k % KA, 1]} for k in range(KV)]
+            for k in range(20):
+                v.step(pairs[k])
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for k in range(KV):
+                v.step(pairs[k])
+            torch.cuda.synchronize()
+            dv = time.perf_counter() - tv
+            o_, r_, te_, tr_, inf_ = v.step(pairs[0])
+            assert r_["player_a"].dtype == torch.float32 and bool((r_["player_a"] == -r_["player_b"]).all())
+            assert v.batch.misuse() == 0
+            vec_env = {"api": "VectorSoccerEnv(io='device').step(dict of int8 CUDA tensors)", "steps": KV,
+                       "us_per_step": dv / KV * 1e6, "env_steps_per_s": N * KV / dv,
+                       "bytes_per_env_step": 22, "note": "rewards as float32 / info['p'] / _final_observation are computed on access"}
+            v.close()
+
     if rank == 0:
         launch_s = ev_ms * 1e-3 / K
         achieved = ALGO_BYTES_PER_ENV_STEP * N / launch_s / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")   # from a separate rocprofv3 --pmc run
-        if os.path.exists(tfile) and N == (1 << 20) and args.slip == 0.0:   # measured for exactly this workload
+        # HBM-side bytes per launch: from a separate rocprofv3 --pmc run (tools/collect_profile.py), reported only when
+        # that run measured THIS workload with THESE kernel sources (sha256 of csrc/ recorded next to the number)
+        traffic, traffic_source = None, None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile) and N == (1 << 20) and args.slip == 0.0:
             try:
-                traffic = json.load(open(tfile)).get("step_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic_source = {"file": "profiles/traffic.json", "profile": tj.get("build"), "commit": tj.get("commit"),
+                                  "kernel": tj.get("kernel"), "csrc_sha256": tj.get("csrc_sha256"),
+                                  "matches_this_build": tj.get("csrc_sha256") == csrc_sha256()}
+                if traffic_source["matches_this_build"]:
+                    traffic = tj.get("step_kernel_hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         out = {
             "metric": "env-steps/sec (whole node) at batch=1M random joint actions; HBM GB/s vs peak",
             "value": world * N * K / wall, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -327,9 +372,12 @@ def main():
                        "lanes_per_gpu": N, "global_lanes": world * N, "slip_prob": args.slip,
                        "parallelism": "independent lane shards x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "soccer::step_kernel_hot<%s>" % ("true, true|false, false" if args.slip else "false, false, false"), "launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "bound_note": "bytes counted at the L2<->fabric boundary (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits "
+                                       "are included, and the ~%d MB working set of a run fits the 256 MB Infinity Cache when K is small"
+                                       % ((12 * N + 7 * N * K) >> 20),
+                         "kernel": "soccer::step_kernel_swar<false>" if not args.slip else "soccer::step_kernel_hot<true, ...>",
+                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
             "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
                          "gathered_last_returns": int(gathered.numel()),
                          "gathered_mean": float(gathered.to(torch.float32).mean())},
@@ -338,8 +386,11 @@ def main():
             out["fused_rollout"] = rollout
         if selfplay:
             out["selfplay_rollout_config5"] = selfplay
+        if vec_env:
+            out["vector_env_device"] = vec_env
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, args.slip, args.cpu_seconds)
+        out["reference_python"] = REFERENCE_PYTHON
         print(json.dumps(out))
     if graph is not None:
         b.graph_destroy(graph)

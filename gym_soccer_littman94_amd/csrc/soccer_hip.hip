@@ -27,8 +27,6 @@ struct soccer_graph {
     hipGraphExec_t exec = nullptr;
     uint64_t ticks = 0;       // ticks consumed by one replay
     int start_slot = 0;       // tick slot the first captured launch reads
-    bool needs_clean = false; // a captured step took the steady-state kernel before any captured full reset
-    bool sets_clean = false;  // the sequence contains a full batched_reset of an auto-resetting handle
 };
 
 struct soccer_handle {
@@ -69,11 +67,6 @@ struct soccer_handle {
     uint4* rec_host = nullptr; uint4* rec_dev = nullptr; uint32_t rec_seq = 0;   // soccer_step_scalar's mapped result record
     // byte-parallel step (soccer_swar.hpp)
     swar::Consts swar_c{}; bool swar_ok = false;
-    // "clean": auto-reset is on and every lane has been reset since the state was last written from outside, so no lane
-    // is frozen or stands in a goal tuple — and none will be: the steady-state instantiations may run.
-    bool clean = false;
-    bool cap_clean_saved = false, cap_needs_clean = false, cap_sets_clean = false;
-    bool force_general = false;             // SOCCER_FORCE_GENERAL=1 (A/B measurements)
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
     bool plan_ready = false;
@@ -375,7 +368,6 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     set_key(h, cfg->seed);
     h->swar_ok = swar::fits(R.H, R.W, cfg->max_steps);
     if (h->swar_ok) h->swar_c = swar::make_consts(R.H, R.W, R.goal_lo, R.goal_hi, cfg->max_steps, R.n_isd, R.isd, P.autoreset != 0u);
-    { const char* fg = std::getenv("SOCCER_FORCE_GENERAL"); h->force_general = fg && fg[0] == '1'; }
     h->slip = cfg->slip_prob != 0.0;
     h->E = e ? static_cast<int>(e) : 4;
 
@@ -509,7 +501,6 @@ extern "C" int batched_reset(soccer_handle* h, const uint8_t* mask, const double
     KernelParams P = h->P;
     bind_tick(h, P, 1);
     ResetIO io{mask, u_reset, obs};
-    if (!mask && P.autoreset && !h->mapped) { h->clean = true; if (h->capturing) h->cap_sets_clean = true; }
     const int grid = grid_for(h, P.n);
     if (h->lut_lds) hipLaunchKernelGGL(reset_kernel<true>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, P, io);
     else hipLaunchKernelGGL(reset_kernel<false>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, P, io);
@@ -538,20 +529,16 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
 #undef HOT_ARGS
     } else if (explicit_u) {    // facade / test path: generic instantiations only
         if (vec && shared) launch_step3<true, true, true>(h, P, io); else launch_step3<true, false, false>(h, P, io);
-    } else if (vec && shared && !h->slip && h->swar_ok && !io.last_return && !P.step_stats) {
+    } else if (vec && shared && !h->slip && h->swar_ok && !io.last_return) {
         // slip_prob == 0: the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
         const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
         const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
-        SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.tick_out, P.misuse,
+        const bool full = io.prob_code || io.final_obs || P.step_stats;
+        SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr,
                      io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs};
-        const bool full = io.prob_code || io.final_obs;
-        const bool steady = h->clean && !h->force_general;
-        if (steady && h->capturing && !h->cap_sets_clean) h->cap_needs_clean = true;
 #define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
-        if (steady) { if (full) hipLaunchKernelGGL((step_kernel_swar<false, true>), gh, b, 0, h->stream, SWAR_ARGS);
-                      else hipLaunchKernelGGL((step_kernel_swar<false, false>), gh, b, 0, h->stream, SWAR_ARGS); }
-        else { if (full) hipLaunchKernelGGL((step_kernel_swar<true, true>), gh, b, 0, h->stream, SWAR_ARGS);
-               else hipLaunchKernelGGL((step_kernel_swar<true, false>), gh, b, 0, h->stream, SWAR_ARGS); }
+        if (full) hipLaunchKernelGGL(step_kernel_swar<true>, gh, b, 0, h->stream, SWAR_ARGS);
+        else hipLaunchKernelGGL(step_kernel_swar<false>, gh, b, 0, h->stream, SWAR_ARGS);
 #undef SWAR_ARGS
     } else if (vec && shared) {
         // the hot instantiations of the per-lane kernel (slip handles, pitches beyond the byte arithmetic);
@@ -693,7 +680,6 @@ extern "C" int soccer_set_state(soccer_handle* h, const int8_t* row_a, const int
     if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_set_state during graph capture");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->clean = false;                       // tuples and flags now come from outside
     const size_t n = h->P.n, S = h->state_stride;
     const Rules& R = h->rules;
     // current device copy of whatever is not supplied, so the resulting tuple can be validated
@@ -891,7 +877,6 @@ static int scalar_call(soccer_handle* h, const char* what, uint32_t op, soccer_s
         std::memset(h->rec_host, 0, 64);
         HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rec_dev), h->rec_host, 0));
     }
-    h->clean = false;
     k.seq = ++h->rec_seq ? h->rec_seq : ++h->rec_seq;                    // never 0
     k.record = h->rec_dev;
     KernelParams P = h->P;
@@ -1304,7 +1289,7 @@ extern "C" int soccer_graph_begin(soccer_handle* h) {
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->capturing = true; h->capture_ticks = 0; h->capture_calls = 0;
     h->capture_start_slot = h->tick_slot;
-    h->cap_clean_saved = h->clean; h->cap_needs_clean = false; h->cap_sets_clean = false;
+
     return SOCCER_OK;
 }
 
@@ -1312,7 +1297,6 @@ extern "C" int soccer_graph_end(soccer_handle* h, soccer_graph** out) {
     if (!h || !out) return fail(h, SOCCER_E_INVALID, "handle/out is NULL");
     if (!h->capturing) return fail(h, SOCCER_E_STATE, "no graph capture in progress");
     h->capturing = false;
-    h->clean = h->cap_clean_saved;          // nothing that was captured has run yet
     hipGraph_t graph = nullptr;
     HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
     if (h->capture_calls % 2 != 0) {
@@ -1324,7 +1308,6 @@ extern "C" int soccer_graph_end(soccer_handle* h, soccer_graph** out) {
     }
     soccer_graph* g = new soccer_graph();
     g->graph = graph; g->ticks = h->capture_ticks; g->start_slot = h->capture_start_slot;
-    g->needs_clean = h->cap_needs_clean; g->sets_clean = h->cap_sets_clean;
     hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(graph); delete g;
@@ -1342,10 +1325,6 @@ extern "C" int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t re
     if (!h || !g) return fail(h, SOCCER_E_INVALID, "handle/graph is NULL");
     if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_graph_launch during graph capture");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (replays > 0 && g->needs_clean && !h->clean)
-        return fail(h, SOCCER_E_STATE, "this graph was captured while every lane was known to be reset (steady-state kernels); "
-                                       "the state has been written from outside since (soccer_set_state): reset all lanes or capture again");
-    if (replays > 0 && g->sets_clean) h->clean = true;
     if (replays > 0 && h->tick_slot != g->start_slot) {
         // launches issued since the capture left the tick in the other slot: move it across
         HIP_TRY(h, hipMemcpyAsync(h->d_tick + (g->start_slot ? 16 : 0), h->d_tick + (h->tick_slot ? 16 : 0),

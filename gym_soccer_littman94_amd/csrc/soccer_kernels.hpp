@@ -570,22 +570,24 @@ template <bool EARLY>
 struct HistAcc {
     uint32_t fin, pos, neg;     // this thread's finished episodes: all / return +1 / return -1
     ulonglong2 old01; unsigned long long old2;   // EARLY only: the wave's slot as of kernel entry (lane 0)
-    __device__ __forceinline__ unsigned long long* slot(const KernelParams& P) const {
+    __device__ __forceinline__ unsigned long long* slot_at(unsigned long long* base) const {
         const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        return P.hist + (size_t)(wave % kHistSlots) * kHistStride;
+        return base + (size_t)(wave % kHistSlots) * kHistStride;
     }
+    __device__ __forceinline__ unsigned long long* slot(const KernelParams& P) const { return slot_at(P.hist); }
     // Every wave of a launch owns one slot and launches are stream-ordered, so plain loads and stores
     // accumulate without atomics.
-    __device__ __forceinline__ void init(const KernelParams& P) {
+    __device__ __forceinline__ void init_at(unsigned long long* base) {
         fin = 0u; pos = 0u; neg = 0u;
         if (EARLY) {
             old01 = make_ulonglong2(0ull, 0ull); old2 = 0ull;
             if ((threadIdx.x & 63u) == 0u) {
-                const unsigned long long* h = slot(P);
+                const unsigned long long* h = slot_at(base);
                 old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2];
             }
         }
     }
+    __device__ __forceinline__ void init(const KernelParams& P) { init_at(P.hist); }
     __device__ __forceinline__ void add(uint32_t finished, int32_t reward) {
         fin += finished; pos += reward > 0 ? 1u : 0u; neg += reward < 0 ? 1u : 0u;
     }
@@ -595,10 +597,11 @@ struct HistAcc {
         fin += finished; pos += (nonzero + (uint32_t)reward_sum) >> 1; neg += (nonzero - (uint32_t)reward_sum) >> 1;
     }
     // Call once at kernel exit, where every lane of the wave is active.
-    __device__ __forceinline__ void flush(const KernelParams& P) {
+    __device__ __forceinline__ void flush(const KernelParams& P) { flush_at(P.hist); }
+    __device__ __forceinline__ void flush_at(unsigned long long* base) {
         const uint32_t tot = wave_sum(fin), p = wave_sum(pos), n = wave_sum(neg);
         if ((threadIdx.x & 63u) == 0u && tot) {
-            unsigned long long* h = slot(P);
+            unsigned long long* h = slot_at(base);
             if (!EARLY) { old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2]; }
             *reinterpret_cast<ulonglong2*>(h) = make_ulonglong2(old01.x + n, old01.y + (tot - p - n));
             h[2] = old2 + p;
@@ -914,57 +917,76 @@ struct SwarParams {
     swar::Consts C;
     uint32_t key0, key1;
     unsigned long long lane_offset;
+    unsigned long long first;               // first lane (within the handle) this launch covers; multiple of 4
     unsigned long long* tick_out;
     unsigned int* misuse;                   // [0] a frozen lane was stepped (:376), [1] an action byte outside 0..4 (:393)
+    unsigned long long* hist;               // FULL: episode histogram slots (SOCCER_F_STEP_STATS), or nullptr
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs;
 };
 
-template <bool GENERAL, bool FULL>
+// FULL: also final_obs / prob_code (VectorSoccerEnv's info) and, when Q.hist is set, the episode histogram.
+// Launch shape (tools/swar_sweep.sh, profiles/r02_sweep.md): one 4-lane group per thread with non-temporal dword
+// accesses measured best; 8 or 16 lanes per thread (dwordx2 / dwordx4), plain or write-through stores and 512-thread
+// workgroups were all equal or slower, and an instantiation without the frozen-lane / goal-tuple code was not faster
+// (the kernel is bound by launch + memory latency, not by vector issue any more).
+template <bool FULL>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
                                                            const unsigned long long* tick_in,
                                                            unsigned long long n, unsigned long long tick_val,
                                                            const SwarParams Q) {
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    const unsigned long long i0 = g << 2;
-    if (i0 >= n) return;                                            // n is a multiple of 4 here; the first lane is 0
-    const uint8_t* sp = state_in + i0;
-    swar::Group S;
-    S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp));
-    S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + state_stride));
-    S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 2 * state_stride));
-    S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 3 * state_stride));
-    S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 4 * state_stride));
-    S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 5 * state_stride));
-    const uint32_t aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_a + i0));
-    const uint32_t ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_b + i0));
-    // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
-    const unsigned long long tick = tick_in ? *tick_in : tick_val;
-    if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
-    const unsigned long long q = (Q.lane_offset + i0) >> 2;         // the thread's 4 lanes are exactly one Philox block
-    const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), Q.key0, Q.key1);
-    swar::Out o;
-    swar::step4<GENERAL, FULL, false>(Q.C, S, aa, ab, 0u, 0u, 0u, 0u, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
-    uint8_t* sw = const_cast<uint8_t*>(sp);
-    __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
-    __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(sw + state_stride));
-    __builtin_nontemporal_store(S.rb, reinterpret_cast<uint32_t*>(sw + 2 * state_stride));
-    __builtin_nontemporal_store(S.cb, reinterpret_cast<uint32_t*>(sw + 3 * state_stride));
-    __builtin_nontemporal_store(S.ps, reinterpret_cast<uint32_t*>(sw + 4 * state_stride));
-    __builtin_nontemporal_store(S.tt, reinterpret_cast<uint32_t*>(sw + 5 * state_stride));
-    if (Q.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
-                                           reinterpret_cast<unsigned long long*>(Q.obs + i0));
-    if (Q.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(Q.reward + i0));
-    if (Q.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(Q.terminated + i0));
-    if (Q.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(Q.truncated + i0));
-    if (FULL) {
-        if (Q.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(Q.prob_code + i0));
-        if (Q.final_obs) __builtin_nontemporal_store((unsigned long long)o.fin_lo | ((unsigned long long)o.fin_hi << 32),
-                                                     reinterpret_cast<unsigned long long*>(Q.final_obs + i0));
+    const bool active = (g << 2) < n;                                // n is a multiple of 4 here
+    if (!FULL && !active) return;
+    HistAcc<true> hist;
+    const bool stats = FULL && Q.hist != nullptr;                    // wave-uniform
+    if (FULL) { hist.fin = 0u; hist.pos = 0u; hist.neg = 0u; hist.old01 = make_ulonglong2(0ull, 0ull); hist.old2 = 0ull; }
+    if (stats) hist.init_at(Q.hist);
+    if (active) {
+        const unsigned long long i0 = Q.first + (g << 2);
+        const uint8_t* sp = state_in + i0;
+        swar::Group S;
+        S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp));
+        S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + state_stride));
+        S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 2 * state_stride));
+        S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 3 * state_stride));
+        S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 4 * state_stride));
+        S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 5 * state_stride));
+        const uint32_t aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_a + i0));
+        const uint32_t ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_b + i0));
+        // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
+        const unsigned long long tick = tick_in ? *tick_in : tick_val;
+        if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
+        const unsigned long long q = (Q.lane_offset + i0) >> 2;     // the thread's 4 lanes are exactly one Philox block
+        const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), Q.key0, Q.key1);
+        swar::Out o;
+        swar::step4<true, FULL, false>(Q.C, S, aa, ab, 0u, 0u, 0u, 0u, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        uint8_t* sw = const_cast<uint8_t*>(sp);
+        __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
+        __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(sw + state_stride));
+        __builtin_nontemporal_store(S.rb, reinterpret_cast<uint32_t*>(sw + 2 * state_stride));
+        __builtin_nontemporal_store(S.cb, reinterpret_cast<uint32_t*>(sw + 3 * state_stride));
+        __builtin_nontemporal_store(S.ps, reinterpret_cast<uint32_t*>(sw + 4 * state_stride));
+        __builtin_nontemporal_store(S.tt, reinterpret_cast<uint32_t*>(sw + 5 * state_stride));
+        if (Q.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
+                                               reinterpret_cast<unsigned long long*>(Q.obs + i0));
+        if (Q.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(Q.reward + i0));
+        if (Q.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(Q.terminated + i0));
+        if (Q.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(Q.truncated + i0));
+        if (FULL) {
+            if (Q.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(Q.prob_code + i0));
+            if (Q.final_obs) __builtin_nontemporal_store((unsigned long long)o.fin_lo | ((unsigned long long)o.fin_hi << 32),
+                                                         reinterpret_cast<unsigned long long*>(Q.final_obs + i0));
+            // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends the episode
+            if (stats) hist.add_totals((uint32_t)__builtin_popcount(o.finished & swar::K80),
+                                       (int32_t)__builtin_popcount(o.rew & swar::K01) - 2 * (int32_t)__builtin_popcount(o.rew & swar::K80),
+                                       (uint32_t)__builtin_popcount(o.rew & swar::K01));
+        }
+        if (o.frozen) Q.misuse[0] = 1u;
+        if (o.bad_action) Q.misuse[1] = 1u;
     }
-    if (GENERAL && o.frozen) Q.misuse[0] = 1u;
-    if (o.bad_action) Q.misuse[1] = 1u;
+    if (stats) hist.flush_at(Q.hist);
 }
 
 // =================================================================================================

@@ -25,25 +25,53 @@ from ..core import SoccerBatch
 AGENTS = ('player_a', 'player_b')
 
 
-class _LazyInfo(dict):
-    """info[agent] in device mode: 'p' (a gather + a cast on the device) is computed on first access, so a
-    rollout loop that never looks at it does not pay two extra kernel launches per step."""
-    def __init__(self, make_p):
-        super().__init__()
-        self._make_p = make_p
+class _Lazy(dict):
+    """A dict whose values are computed on first access (and cached until `invalidate()`): device mode returns one
+    of these for everything that would cost an extra kernel launch per step — `info[agent]["p"]` (a gather + a
+    cast), the float32 rewards (a cast; a negation for player_b) and `infos["_final_observation"]` (an OR) — so a
+    rollout loop that does not look at them pays one launch per step and nothing else."""
+    def __init__(self, thunks, eager=None):
+        super().__init__(eager or {})
+        self._thunks = thunks
+        self._eager = dict(eager or {})
+
+    def invalidate(self):
+        dict.clear(self)
+        dict.update(self, self._eager)
 
     def __missing__(self, key):
-        if key != "p":
+        if key not in self._thunks:
             raise KeyError(key)
-        v = self._make_p()
+        v = self._thunks[key]()
         self[key] = v
         return v
 
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
     def __contains__(self, key):
-        return key == "p" or super().__contains__(key)
+        return key in self._thunks or dict.__contains__(self, key)
 
     def keys(self):
-        return {"p"}.union(super().keys())
+        return list(dict.fromkeys(list(self._eager) + list(self._thunks)))
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
+class _LazyInfo(_Lazy):
+    """info[agent]: 'p' computed on first access."""
+    def __init__(self, make_p):
+        super().__init__({"p": make_p})
 
 
 class VectorSoccerEnv:
@@ -98,6 +126,29 @@ class VectorSoccerEnv:
             self._term = t.zeros(n, dtype=t.uint8, device=d); self._trunc = t.zeros(n, dtype=t.uint8, device=d)
             self._code = t.zeros(n, dtype=t.uint8, device=d)
             self._prob = t.tensor(np.round(b.prob_table, 2), dtype=t.float64, device=d)
+            # Everything step() returns is built ONCE: the result buffers are fixed, so the dicts of views over them
+            # are too (the reference also hands back the same dict objects every call); what needs a kernel of its
+            # own is computed on first access.  step() itself = one ctypes call = one kernel launch.
+            ags = self.return_agent
+            term_b, trunc_b = self._term.view(t.bool), self._trunc.view(t.bool)      # 0/1 bytes: reinterpret, no kernel
+            self._ret_obs = {ag: self._obs for ag in ags}
+            self._ret_term = {ag: term_b for ag in ags}
+            self._ret_trunc = {ag: trunc_b for ag in ags}
+            rew_thunks = {}
+            if 'player_a' in ags: rew_thunks['player_a'] = lambda: self._rew.to(t.float32)
+            if 'player_b' in ags: rew_thunks['player_b'] = lambda: -self._rew.to(t.float32)      # :400-402, :243-244
+            self._ret_rew = _Lazy(rew_thunks)
+            self._ret_p = _LazyInfo(lambda: self._prob[self._code.long()])       # np.round(prob, 2) of the sampled transition (:405)
+            eager = {ag: self._ret_p for ag in ags}
+            eager["final_observation"] = {ag: self._fin for ag in ags}
+            self._ret_infos = _Lazy({"_final_observation": lambda: term_b | trunc_b}, eager)
+            from .._lib import StepArgs
+            self._step_args = StepArgs(None, None, None, None, self._obs.data_ptr(), self._rew.data_ptr(),
+                                       self._term.data_ptr(), self._trunc.data_ptr(), self._code.data_ptr(),
+                                       self._fin.data_ptr(), None)
+            self._step_call = b.lib.batched_step_ex
+            import ctypes
+            self._step_ref = ctypes.byref(self._step_args)
 
     # ---------------------------------------------------------------------------------------------
     def reset(self, seed=None, options=None, mask=None):
@@ -173,18 +224,20 @@ class VectorSoccerEnv:
         t = self._torch
         for x in (a, bb):
             assert x is None or (x.dtype == t.int8 and x.is_cuda and x.shape == (n,) and x.is_contiguous()), \
-                "device io expects contiguous torch.int8 CUDA tensors (values 0..4; not re-validated on the hot path)"
-        b.step(a, bb, obs=self._obs, reward=self._rew, terminated=self._term, truncated=self._trunc,
-               prob_code=self._code, final_obs=self._fin)
-        r = self._rew.to(t.float32)
-        term = self._term.view(t.bool); trunc = self._trunc.view(t.bool)     # 0/1 bytes: reinterpret, no kernel
-        ags = self.return_agent
-        lazy = _LazyInfo(lambda: self._prob[self._code.long()])
-        infos = {ag: lazy for ag in ags}
-        infos["final_observation"] = {ag: self._fin for ag in ags}
-        infos["_final_observation"] = term | trunc
-        return ({ag: self._obs for ag in ags}, self._rewards(r),
-                {ag: term for ag in ags}, {ag: trunc for ag in ags}, infos)
+                "device io expects contiguous torch.int8 CUDA tensors"
+        # action VALUES are not read back on this path: a byte outside 0..4 executes as NOOP-or-(value & 7) inside the
+        # pitch (never an out-of-table access) and raises the sticky misuse flag (`self.batch.misuse() & 2`)
+        args = self._step_args
+        args.act_a = a.data_ptr() if a is not None else None
+        args.act_b = bb.data_ptr() if bb is not None else None
+        b._check(self._step_call(b.h, self._step_ref))
+        self._ret_rew.invalidate(); self._ret_p.invalidate(); self._ret_infos.invalidate()
+        return self._ret_obs, self._ret_rew, self._ret_term, self._ret_trunc, self._ret_infos
+
+    @property
+    def reward_int8(self):
+        """device io: player A's reward of the last step as the int8 tensor the kernel wrote (-1 / 0 / +1), no cast."""
+        return self._rew
 
     def _raise_on_misuse(self):
         if self._batch.misuse():

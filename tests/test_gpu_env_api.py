@@ -428,12 +428,13 @@ def test_vector_env_without_autoreset_is_strict_like_the_reference():
     v.close()
 
 
-def test_vector_env_device_io_matches_numpy_io():
+@pytest.mark.parametrize("slip", [0.2, 0.0])
+def test_vector_env_device_io_matches_numpy_io(slip):
     import torch
     n, T = 4096, 60
     rng = np.random.default_rng(4)
-    vn = VectorSoccerEnv(n, slip_prob=0.2, seed=21)
-    vd = VectorSoccerEnv(n, slip_prob=0.2, seed=21, io="device")
+    vn = VectorSoccerEnv(n, slip_prob=slip, seed=21)
+    vd = VectorSoccerEnv(n, slip_prob=slip, seed=21, io="device")
     on, _ = vn.reset(); od, _ = vd.reset()
     np.testing.assert_array_equal(on['player_a'], od['player_a'].cpu().numpy().astype(np.uint16))
     for k in range(T):
@@ -447,6 +448,14 @@ def test_vector_env_device_io_matches_numpy_io():
         np.testing.assert_array_equal(rn[3]['player_a'], rd[3]['player_a'].cpu().numpy())
         np.testing.assert_array_equal(rn[4]['player_a']['p'], rd[4]['player_a']['p'].cpu().numpy())
         np.testing.assert_array_equal(rn[4]["_final_observation"], rd[4]["_final_observation"].cpu().numpy())
+        np.testing.assert_array_equal(rn[4]["final_observation"]['player_b'],
+                                      rd[4]["final_observation"]['player_b'].cpu().numpy().astype(np.uint16))
+        np.testing.assert_array_equal(rn[1]['player_a'], rd[1]['player_a'].cpu().numpy())
+        assert rd[1]['player_a'].dtype == torch.float32 and rd[2]['player_b'].dtype == torch.bool
+        assert set(rd[4].keys()) == {'player_a', 'player_b', 'final_observation', '_final_observation'}
+        np.testing.assert_array_equal(vd.reward_int8.cpu().numpy(), rn[1]['player_a'].astype(np.int8))
+    np.testing.assert_array_equal(vn.episode_histogram(), vd.episode_histogram())
+    assert vn.episode_histogram().sum() > 0
     vn.close(); vd.close()
 
 

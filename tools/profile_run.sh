@@ -1,0 +1,29 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun): the rocprofv3 passes behind profiles/<tag>_*.  Usage: tools/profile_run.sh r02_a
+#   kt     kernel trace + stats of the default bench command (timing; the bench line of the same run is kept)
+#   fetch / write   FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+#   sq1 / sq2       SQ instruction / wait counters
+# Counters are collected with --kernel-trace only (never with the runtime / hip trace domains).
+set -e
+TAG=${1:-r02}
+ROOTDIR="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOTDIR/gpurun_out/prof_$TAG"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="$ROOTDIR/bench.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o runc -- python3 "$B" --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/kt.err"
+echo "kt done"
+PMC_ARGS="--steps 100 --warmup 10 --no-cpu-baseline --rollout 20 --no-vector-env"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o runc -- python3 "$B" $PMC_ARGS > "$OUT/fetch.json" 2> "$OUT/fetch.err"
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o runc -- python3 "$B" $PMC_ARGS > "$OUT/write.json" 2> "$OUT/write.err"
+echo "write done"
+SQ_ARGS="--steps 60 --warmup 10 --no-cpu-baseline --rollout 20 --no-vector-env"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d "$OUT/sq1" -o runc -- python3 "$B" $SQ_ARGS > "$OUT/sq1.json" 2> "$OUT/sq1.err"
+echo "sq1 done"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$OUT/sq2" -o runc -- python3 "$B" $SQ_ARGS > "$OUT/sq2.json" 2> "$OUT/sq2.err"
+echo "sq2 done"
+# un-profiled reference run of the same command as kt (a profiled run clocks lower)
+python3 "$B" --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/bench_unprofiled.json" 2>/dev/null
+python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_driver_shape.json" 2>/dev/null
+echo "all done"
