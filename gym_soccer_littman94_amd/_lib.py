@@ -99,6 +99,7 @@ PROTOTYPES = {
     "soccer_prob_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_double * 12)]),
     "soccer_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_uint64)]),
     "soccer_reset_stats": (C.c_int, [C.c_void_p]),
+    "soccer_peek_misuse": (C.c_uint32, [C.c_void_p]),
     "soccer_tick": (C.c_uint64, [C.c_void_p]),
     "soccer_get_seed": (C.c_uint64, [C.c_void_p]),
     "soccer_set_tick": (C.c_int, [C.c_void_p, C.c_uint64]),

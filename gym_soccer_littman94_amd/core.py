@@ -391,11 +391,18 @@ class SoccerBatch:
         self._check(self.lib.soccer_get_stats(self.h, C.byref(hist), C.byref(mis)))
         return np.array(hist, dtype=np.uint64), int(mis.value)
 
+    MISUSE_FROZEN, MISUSE_ACTION = 1, 2
+
     def misuse(self):
-        """The sticky misuse flag alone (no histogram copy): nonzero if a lane was stepped while it needed reset."""
+        """The sticky misuse flags alone (no histogram copy; synchronises): MISUSE_FROZEN if a lane was stepped while
+        it needed reset (:376), MISUSE_ACTION if a device-side action byte was outside 0..4 (:393)."""
         mis = C.c_uint64()
         self._check(self.lib.soccer_get_stats(self.h, None, C.byref(mis)))
         return int(mis.value)
+
+    def peek_misuse(self):
+        """The same flags WITHOUT synchronising: what the launches completed so far have raised."""
+        return int(self.lib.soccer_peek_misuse(self.h))
 
     def reset_stats(self):
         self._check(self.lib.soccer_reset_stats(self.h))

@@ -19,6 +19,7 @@
 #include "../../include/soccer_hip.h"
 #include "soccer_kernels.hpp"
 #include "soccer_rules.hpp"
+#include "soccer_slip.hpp"
 
 using namespace soccer;
 
@@ -60,13 +61,13 @@ struct soccer_handle {
     uint64_t capture_ticks = 0;
     int capture_calls = 0;
     int capture_start_slot = 0;
-    // LDS transition-table rollout (slip 0, table fits the LDS): see rollout_table_kernel
-    uint32_t* d_trans = nullptr; uint16_t* d_code_lut = nullptr; uint32_t* d_code_tuple = nullptr;
-    TransTables TT{}; bool table_ok = false; size_t table_smem = 0; int n_cu = 256;
+    int n_cu = 256;
     uint4* d_sub = nullptr;                 // integer slip thresholds (KernelParams::sub)
     uint4* rec_host = nullptr; uint4* rec_dev = nullptr; uint32_t rec_seq = 0;   // soccer_step_scalar's mapped result record
     // byte-parallel step (soccer_swar.hpp)
     swar::Consts swar_c{}; bool swar_ok = false;
+    swar::SlipConsts slip_c{}; bool slip_swar_ok = false;   // integer slip selection usable by the byte-parallel kernels
+    int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
     bool plan_ready = false;
@@ -109,8 +110,7 @@ static void free_handle(soccer_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev,
-                    h->d_trans, h->d_code_lut, h->d_code_tuple, h->d_sub};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -135,58 +135,6 @@ static hipError_t raise_smem_limit(size_t bytes) {
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<E, SLIP, LUT_LDS, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
-// The (state code, joint action) -> outcome table of rollout_table_kernel, built from the host copies of the
-// move/bounds table and the same classify() the kernels run.  Returns "" or an internal-error message;
-// `fits` says whether codes fit 14 bits (else the table path is simply not used).
-static std::string build_transition_table(const Rules& R, std::vector<uint32_t>& trans, std::vector<uint16_t>& code_lut,
-                                          std::vector<uint32_t>& code_tuple, bool& fits) {
-    const int H = R.H, W = R.W, HW = H * W, nS = R.nS;
-    const size_t T = R.lut.size();
-    code_lut.assign(T, 0xFFFF);
-    int nG = 0;
-    for (size_t f = 0; f < T; ++f) if (R.kind[f] == 2) ++nG;
-    fits = nS + nG <= 0x3fff;
-    if (!fits) return "";
-    code_tuple.assign((size_t)nS + nG, 0);
-    int gid = 0;
-    for (size_t f = 0; f < T; ++f) {
-        if (R.kind[f] == 0) continue;
-        const uint32_t code = R.kind[f] == 2 ? (uint32_t)(nS + gid++) : R.lut[f];
-        const uint32_t p = f & 1, cb = (f >> 1) % HW, ca = (f >> 1) / HW;
-        code_lut[f] = (uint16_t)code;
-        code_tuple[code] = (ca / W) | ((ca % W) << 4) | ((cb / W) << 8) | ((cb % W) << 12) | (p << 16);
-    }
-    auto pos_of = [&](uint32_t cell) { return cell | ((((cell / W) << 8) | (cell % W)) << 16); };
-    auto code_of = [&](uint32_t A, uint32_t B, uint32_t p) { return (uint32_t)code_lut[((size_t)(A & 0xffffu) * HW + (B & 0xffffu)) * 2 + p]; };
-    trans.assign((size_t)nS * 25, 0);
-    for (size_t f = 0; f < T; ++f) {
-        if (R.kind[f] != 1) continue;
-        const uint32_t p = f & 1, cellB = (f >> 1) % HW, cellA = (f >> 1) / HW;
-        const uint32_t A = pos_of(cellA), B = pos_of(cellB), s = R.lut[f];
-        for (uint32_t aa = 0; aa < 5; ++aa) for (uint32_t ab = 0; ab < 5; ++ab) {
-            const uint32_t nA = R.next_cell[((p ^ 1u) * HW + cellA) * 5 + aa], nB = R.next_cell[(p * HW + cellB) * 5 + ab];
-            const Resolved r = classify(A, B, nA, nB, aa, ab);
-            uint32_t n0 = 0, n1 = 0, plus = 0;
-            if (r.kind == K_MOVE) {
-                n0 = code_of(nA, nB, p);
-                if (n0 >= (uint32_t)nS && n0 != 0xFFFF) plus = (((p ? nB : nA) >> 16) & 0xffu) == (uint32_t)(W - 1) ? 1u : 0u;   // :94-98
-            } else if (r.kind == K_FLIP) {
-                n0 = code_of(A, B, p ^ 1u);
-            } else if (r.kind == K_COIN) {
-                n0 = code_of(A, B, 0);
-                if (code_of(A, B, 1) != n0 + 1) return "internal error: possession codes are not consecutive";
-            } else {
-                n0 = code_of(A, nB, 0); n1 = code_of(nA, B, 0);
-                if (code_of(A, nB, 1) != n0 + 1 || code_of(nA, B, 1) != n1 + 1) return "internal error: possession codes are not consecutive";
-                if (n1 >= (uint32_t)nS) return "internal error: a four-way tie reaches a goal tuple";
-            }
-            if (n0 == 0xFFFF || (r.kind != K_MOVE && n0 >= (uint32_t)nS)) return "internal error: a transition leaves the reachable tuples";
-            trans[(size_t)s * 25 + aa * 5 + ab] = n0 | (n1 << 14) | (r.kind << 28) | (plus << 30);
-        }
-    }
-    return "";
 }
 
 extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
@@ -277,98 +225,28 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     P.autoreset = (cfg->flags & SOCCER_F_AUTORESET) ? 1u : 0u;
     P.step_stats = (cfg->flags & SOCCER_F_STEP_STATS) ? 1u : 0u;
     P.isd_shift = R.n_isd == 4 ? 0u : 1u;
-    // slip-combination weights exactly as the reference writes them, left to right in float64 (:211-222)
+    // slip-combination weights, the nominal float64 thresholds of the slip fast path and their integer form
+    // (soccer_slip.hpp: host-only, shared with the CPU test of the byte-parallel slip step)
     {
-        volatile double s = cfg->slip_prob;   // volatile: no reassociation / contraction
-        volatile double one_minus = 1 - s;
-        volatile double c0 = one_minus * one_minus;
-        volatile double c1a = one_minus * s;  volatile double c1 = c1a * 0.5;
-        volatile double c2a = s * one_minus;  volatile double c2 = c2a * 0.5;
-        volatile double c3a = s * s;          volatile double c3 = c3a * 0.25;
-        P.w[0] = c0; P.w[1] = c1; P.w[2] = c2; P.w[3] = c3;
-        // nominal thresholds of the slip fast path: running sum of the active weights in list order
-        static const int cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
-        volatile double acc = 0.0;
-        P.nb = 0; P.act_pack = 0;
-        for (int c = 0; c < 9; ++c) P.B[c] = __builtin_inf();
-        for (int c = 0; c < 9; ++c) {
-            const double wc = P.w[cls[c]];
-            if (wc == 0.0) continue;
-            acc = acc + wc;
-            P.B[P.nb] = acc; P.act_pack |= (unsigned long long)c << (4 * P.nb); ++P.nb;
-        }
-    }
-    // Integer form of the slip decision for Philox draws u = m * 2^-30 (KernelParams::CB / sub): scaling by
-    // 2^30 is exact, so u >= b <=> m >= ceil(b * 2^30).  Allowed only if no scaled threshold lies within 2^-10
-    // of an integer (then no draw can be within 2^-40 of a threshold and the nominal decision is the exact
-    // one) and the last cumulative weight exceeds every possible draw.
-    {
-        static const int cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
-        bool ok = cfg->slip_prob != 0.0 && P.nb >= 1;
-        uint32_t danger[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; int n_danger = 0;
-        // Dyadic slips (0.5, 0.25, 0.75, 1.0 ...): every weight is a short binary fraction and every float64 sum
-        // of the lists is EXACT, so the nominal thresholds ARE the running sums and the integer comparison is the
-        // reference's comparison even when a draw sits exactly on a threshold.  Checked with error-free sums.
-        bool exact = true;
-        auto add_exact = [&](double a, double b) {                      // Fast2Sum: the rounding error of a + b
-            volatile double sum = a + b; volatile double bb = sum - a; volatile double err = (a - (sum - bb)) + (b - bb);
-            if (err != 0.0) exact = false;
-            return (double)sum;
-        };
-        {
-            static const int cls0[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
-            double acc = 0.0;
-            for (int c = 0; c < 9; ++c) {
-                const double wc = P.w[cls0[c]];
-                if (wc == 0.0) continue;
-                double t2 = acc; for (int j = 0; j < 2; ++j) t2 = add_exact(t2, wc * 0.5);     // .5/.5 lists
-                double t4 = acc; for (int j = 0; j < 4; ++j) t4 = add_exact(t4, wc * 0.25);    // .25 x 4 lists
-                acc = add_exact(acc, wc);
-                if (t2 != acc || t4 != acc) exact = false;
-            }
-            volatile double s1 = cfg->slip_prob; volatile double om = 1 - s1;
-            if (add_exact(om, s1) != 1.0) exact = false;
-            // the weight products themselves must be exact too: compare with long double
-            const long double S = cfg->slip_prob, O = 1.0L - S;
-            if ((long double)P.w[0] != O * O || (long double)P.w[1] != O * S * 0.5L || (long double)P.w[2] != S * O * 0.5L ||
-                (long double)P.w[3] != S * S * 0.25L || (long double)(double)O != O) exact = false;
-        }
-        auto scaled = [&](double t, uint32_t& out) {
-            const double x = t * 0x1.0p30;                              // exact
-            if (!(x >= 0.0) || x > 0x1.0p31) { ok = false; out = 0xFFFFFFFFu; return; }
-            const double r = __builtin_nearbyint(x);
-            // a draw m = r (< 2^30) could sit on / next to the threshold: only safe when the sums are exact;
-            // otherwise remember r — a lane that draws it walks the float64 sums (slip_int = 2)
-            if (!exact && __builtin_fabs(x - r) < 0x1.0p-10 && r < 0x1.0p30) {
-                const uint32_t ri = (uint32_t)r;
-                bool seen = false;
-                for (int q = 0; q < n_danger && q < 4; ++q) seen = seen || danger[q] == ri;
-                if (!seen) { if (n_danger < 4) danger[n_danger] = ri; ++n_danger; }
-            }
-            out = (uint32_t)__builtin_ceil(x);
-        };
-        std::vector<uint4> sub(9, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
-        for (int i = 0; i < 9; ++i) P.CB[i] = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < P.nb && i < 9; ++i) {
-            scaled(P.B[i], P.CB[i]);
-            const int c = (int)((P.act_pack >> (4 * i)) & 0xf);
-            volatile double S = i ? P.B[i - 1] : 0.0;
-            volatile double q2 = P.w[cls[c]] * 0.5, q4 = P.w[cls[c]] * 0.25;
-            volatile double a1 = S + q2;                                 // two outcomes: t1
-            volatile double b1 = S + q4; volatile double b2 = b1 + q4; volatile double b3 = b2 + q4;   // four: t1, t2, t3
-            scaled(a1, sub[i].x); scaled(b1, sub[i].y); scaled(b2, sub[i].z); scaled(b3, sub[i].w);
-        }
-        if (ok && P.CB[P.nb - 1] < (1u << 30)) ok = false;             // some draw would fall beyond the last entry
-        P.slip_int = !ok || n_danger > 4 ? 0u : (n_danger ? 2u : 1u);
-        for (int q = 0; q < 4; ++q) P.danger[q] = danger[q];
-        CREATE_TRY(hipMalloc(&h->d_sub, sub.size() * sizeof(uint4)));
-        CREATE_TRY(hipMemcpy(h->d_sub, sub.data(), sub.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        const SlipTables ST = build_slip_tables(cfg->slip_prob);
+        for (int i = 0; i < 4; ++i) P.w[i] = ST.w[i];
+        for (int i = 0; i < 9; ++i) { P.B[i] = ST.B[i]; P.CB[i] = ST.CB[i]; }
+        P.nb = ST.nb; P.act_pack = ST.act_pack; P.slip_int = ST.slip_int;
+        for (int q = 0; q < 4; ++q) P.danger[q] = ST.danger[q];
+        static_assert(sizeof(swar::Quad) == sizeof(uint4), "threshold rows are 16 bytes");
+        CREATE_TRY(hipMalloc(&h->d_sub, sizeof(ST.sub)));
+        CREATE_TRY(hipMemcpy(h->d_sub, ST.sub, sizeof(ST.sub), hipMemcpyHostToDevice));
         P.sub = h->d_sub;
+        h->slip_swar_ok = ST.swar_ok;
+        h->slip_c = swar::SlipConsts{};
+        for (int i = 0; i < 9; ++i) h->slip_c.CB[i] = ST.CB[i];
+        h->slip_c.c_off = ST.c_off;
     }
     set_key(h, cfg->seed);
     h->swar_ok = swar::fits(R.H, R.W, cfg->max_steps);
     if (h->swar_ok) h->swar_c = swar::make_consts(R.H, R.W, R.goal_lo, R.goal_hi, cfg->max_steps, R.n_isd, R.isd, P.autoreset != 0u);
     h->slip = cfg->slip_prob != 0.0;
+    if (const char* e2 = std::getenv("SOCCER_ROLLOUT")) h->rollout_pref = std::atoi(e2);
     h->E = e ? static_cast<int>(e) : 4;
 
     // Observation table (uint16 index < 65535 bounds it to a few hundred KB): global for the step kernel,
@@ -400,34 +278,6 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
     h->grid_cap = prop.multiProcessorCount * 8;
     h->n_cu = prop.multiProcessorCount;
-    if (!h->slip || P.slip_int == 1u) {     // LDS transition table for batched_rollout, when it fits (slip: integer decision only)
-        std::vector<uint32_t> trans, code_tuple; std::vector<uint16_t> code_lut; bool fits = false;
-        const std::string terr = build_transition_table(R, trans, code_lut, code_tuple, fits);
-        if (!terr.empty()) { free_handle(h); return fail(nullptr, SOCCER_E_INVALID, "%s", terr.c_str()); }
-        size_t smem = (trans.size() + kTblHead) * sizeof(uint32_t);
-        const size_t with_mix = ((smem + 15) & ~size_t(15)) + 2 * (size_t)R.nS * sizeof(uint2) + 2 * (((size_t)R.nS + 15) & ~size_t(15));
-        const bool mix_lds = with_mix <= 150 * 1024;
-        if (mix_lds) smem = with_mix;
-        if (fits && smem <= 150 * 1024) {
-            CREATE_TRY(hipMalloc(&h->d_trans, trans.size() * 4 + 16));
-            CREATE_TRY(hipMemcpy(h->d_trans, trans.data(), trans.size() * 4, hipMemcpyHostToDevice));
-            CREATE_TRY(hipMalloc(&h->d_code_lut, code_lut.size() * 2));
-            CREATE_TRY(hipMemcpy(h->d_code_lut, code_lut.data(), code_lut.size() * 2, hipMemcpyHostToDevice));
-            CREATE_TRY(hipMalloc(&h->d_code_tuple, code_tuple.size() * 4));
-            CREATE_TRY(hipMemcpy(h->d_code_tuple, code_tuple.data(), code_tuple.size() * 4, hipMemcpyHostToDevice));
-            h->TT = TransTables{h->d_trans, h->d_code_lut, h->d_code_tuple, R.nS, (int32_t)code_tuple.size(), mix_lds ? 1 : 0};
-            h->table_smem = smem;
-            hipError_t se = hipSuccess;
-#define RAISE_T(EV, DV) if (se == hipSuccess) se = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_table_kernel<EV, DV, false>), \
-                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-                        if (se == hipSuccess) se = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_table_kernel<EV, DV, true>), \
-                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            RAISE_T(1, false) RAISE_T(1, true) RAISE_T(4, false) RAISE_T(4, true)
-#undef RAISE_T
-            CREATE_TRY(se);
-            h->table_ok = true;
-        }
-    }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     *out = h;
@@ -519,7 +369,24 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
     const bool shared = ((P.lane_offset + P.first) & 3ull) == 0ull;
     const bool policy_only = explicit_u && !io.u_step && !io.u_reset;       // fixed-policy handle, Philox draws
     const bool lean0 = !io.prob_code && !io.final_obs && !io.last_return && !P.step_stats;
-    if (policy_only && vec && shared && lean0) {                            // the hot kernel with the policy lookup
+    const bool swar_fit = vec && shared && h->swar_ok && (!h->slip || h->slip_swar_ok) && !io.last_return;
+    if ((policy_only || !explicit_u) && swar_fit) {
+        // the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
+        const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
+        const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
+        const bool full = io.prob_code || io.final_obs || P.step_stats;
+        SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr,
+                     h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.policy_a, P.policy_b,
+                     io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs};
+#define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
+#define SWAR_GO(FV, SV, PV) hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV>), gh, b, 0, h->stream, SWAR_ARGS)
+        if (policy_only) { if (h->slip) { if (full) SWAR_GO(true, true, true); else SWAR_GO(false, true, true); }
+                           else { if (full) SWAR_GO(true, false, true); else SWAR_GO(false, false, true); } }
+        else { if (h->slip) { if (full) SWAR_GO(true, true, false); else SWAR_GO(false, true, false); }
+               else { if (full) SWAR_GO(true, false, false); else SWAR_GO(false, false, false); } }
+#undef SWAR_GO
+#undef SWAR_ARGS
+    } else if (policy_only && vec && shared && lean0) {                     // the per-lane hot kernel with the policy lookup
         const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
         const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
 #define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), P, io
@@ -529,17 +396,6 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
 #undef HOT_ARGS
     } else if (explicit_u) {    // facade / test path: generic instantiations only
         if (vec && shared) launch_step3<true, true, true>(h, P, io); else launch_step3<true, false, false>(h, P, io);
-    } else if (vec && shared && !h->slip && h->swar_ok && !io.last_return) {
-        // slip_prob == 0: the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
-        const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
-        const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
-        const bool full = io.prob_code || io.final_obs || P.step_stats;
-        SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr,
-                     io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs};
-#define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
-        if (full) hipLaunchKernelGGL(step_kernel_swar<true>, gh, b, 0, h->stream, SWAR_ARGS);
-        else hipLaunchKernelGGL(step_kernel_swar<false>, gh, b, 0, h->stream, SWAR_ARGS);
-#undef SWAR_ARGS
     } else if (vec && shared) {
         // the hot instantiations of the per-lane kernel (slip handles, pitches beyond the byte arithmetic);
         // LEAN drops the code for prob_code / final_obs / last_return / step stats
@@ -640,6 +496,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
     // one launch covers at most kChunk steps (per-thread episode counters are 16 bit wide); the tick
     // sequence of consecutive launches is contiguous, so chunking does not change any result
     constexpr int kChunk = 4096;
+    const Rules& R0 = h->rules;
     for (int s0 = 0; s0 < a->n_steps; s0 += kChunk) {
         const int ns = a->n_steps - s0 < kChunk ? a->n_steps - s0 : kChunk;
         KernelParams P = h->P;
@@ -649,19 +506,28 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                      (long long)a->act_stride, a->obs ? a->obs + oo : nullptr, a->reward ? a->reward + oo : nullptr,
                      a->terminated ? a->terminated + oo : nullptr, a->truncated ? a->truncated + oo : nullptr,
                      (long long)a->out_stride, a->return_sum, a->episode_count};
-        if (h->table_ok) {      // slip 0 and the transition table fits the LDS: one gather per env-step
+        // the byte-parallel rollout: every pitch that fits the byte arithmetic, slip 0 or an exact integer slip decision
+        const bool swar_roll = h->swar_ok && (!h->slip || h->slip_swar_ok) && (P.n & 3ull) == 0ull && ((P.lane_offset + P.first) & 3ull) == 0ull &&
+                               ok(4) && h->rollout_pref != 1;
+        if (swar_roll) {
             const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
-            const int ET = E >= 4 ? 4 : 1;
-            const uint64_t groups = (P.n + ET - 1) / ET;
-            uint64_t blocks = (groups + kTblBlock - 1) / kTblBlock;
-            if (blocks > (uint64_t)h->n_cu) blocks = h->n_cu;
-            const dim3 g((unsigned)blocks), bl(kTblBlock);
-#define LAUNCH_T(EV, DV, SV) hipLaunchKernelGGL((rollout_table_kernel<EV, DV, SV>), g, bl, h->table_smem, h->stream, P, io, h->TT)
-            if (h->slip) { if (ET == 4) { if (dyn) LAUNCH_T(4, true, true); else LAUNCH_T(4, false, true); }
-                           else { if (dyn) LAUNCH_T(1, true, true); else LAUNCH_T(1, false, true); } }
-            else { if (ET == 4) { if (dyn) LAUNCH_T(4, true, false); else LAUNCH_T(4, false, false); }
-                   else { if (dyn) LAUNCH_T(1, true, false); else LAUNCH_T(1, false, false); } }
-#undef LAUNCH_T
+            RolloutSwar RS{P.state, P.state_stride, P.first, P.n, P.lane_offset, P.tick_in, P.tick_out, P.hist, P.misuse,
+                           P.policy_a, P.policy_b, P.key0, P.key1,
+                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), R0.nS, 0};
+            size_t smem = 36 * sizeof(uint32_t);
+            if (dyn) {
+                const size_t need = smem + 2 * (size_t)R0.nS * sizeof(uint2) + 2 * (((size_t)R0.nS + 15) & ~size_t(15));
+                if (need <= 64 * 1024) { RS.lds_tables = 1; smem = need; }
+            }
+            const uint64_t groups = P.n >> 2;
+            uint64_t blocks = (groups + kBlock - 1) / kBlock;
+            if (blocks > (uint64_t)h->grid_cap) blocks = h->grid_cap;
+            const dim3 g((unsigned)blocks), bl(kBlock);
+#define LAUNCH_S(DV, SV) do { if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+                              hipLaunchKernelGGL((rollout_swar_kernel<DV, SV>), g, bl, smem, h->stream, RS, io); } while (0)
+            if (h->slip) { if (dyn) LAUNCH_S(true, true); else LAUNCH_S(false, true); }
+            else { if (dyn) LAUNCH_S(true, false); else LAUNCH_S(false, false); }
+#undef LAUNCH_S
         } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;
             case 4: launch_rollout<4>(h, P, io); break;
@@ -796,6 +662,17 @@ extern "C" int soccer_staging(soccer_handle* h, soccer_staging_view* v) {
     return SOCCER_OK;
 }
 
+// every action byte of a host array must be 0..4 (the reference indexes ACTION_STRING with it: IndexError, :393)
+static long first_bad_action(const int8_t* a, size_t n) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {                    // eight bytes at a time: any bit above 2 set, or 5..7
+        uint64_t v; std::memcpy(&v, a + i, 8);
+        if ((v & 0xF8F8F8F8F8F8F8F8ull) | (((v & 0x0707070707070707ull) + 0x0303030303030303ull) & 0x0808080808080808ull)) break;
+    }
+    for (; i < n; ++i) if (a[i] < 0 || a[i] > 4) return (long)i;
+    return -1;
+}
+
 extern "C" int batched_step_staged(soccer_handle* h, uint32_t use) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (h->capturing) return fail(h, SOCCER_E_STATE, "batched_step_staged during graph capture");
@@ -807,6 +684,12 @@ extern "C" int batched_step_staged(soccer_handle* h, uint32_t use) {
     const StageLayout L = stage_layout(n);
     if (int rc = ensure_stage(h, L)) return rc;
     uint8_t* H = h->stage_host; uint8_t* D = h->stage_dev;
+    for (int pl = 0; pl < 2; ++pl) {
+        if (!(pl ? has_b : has_a)) continue;
+        const long bad = first_bad_action(reinterpret_cast<const int8_t*>(H + (pl ? L.act_b : L.act_a)), n);
+        if (bad >= 0) return fail(h, SOCCER_E_INVALID, "batched_step: action of player_%c in lane %ld is %d; actions must be in 0..4",
+                                  pl ? 'b' : 'a', bad, (int)reinterpret_cast<const int8_t*>(H + (pl ? L.act_b : L.act_a))[bad]);
+    }
     if (!h->mapped) {           // only what this call uses crosses the bus
         if (has_a && has_b) HIP_TRY(h, hipMemcpyAsync(D + L.act_a, H + L.act_a, L.act_b + n - L.act_a, hipMemcpyHostToDevice, h->stream));
         else if (has_a) HIP_TRY(h, hipMemcpyAsync(D + L.act_a, H + L.act_a, n, hipMemcpyHostToDevice, h->stream));
@@ -886,8 +769,14 @@ static int scalar_call(soccer_handle* h, const char* what, uint32_t op, soccer_s
     HIP_TRY(h, hipGetLastError());
     volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->rec_host);
     const auto t_start = std::chrono::steady_clock::now();
-    // complete record: word 0 == seq and the high half of word 3 == seq's low half (both ends of the one store)
-    auto landed = [&]() { return flag[0] == k.seq && (flag[3] >> 16) == (k.seq & 0xffffu); };
+    // complete record: word 0 == seq and the top byte of word 3 == seq's low byte (both ends of the one store)
+    // ... and the check byte in word 3 is the byte-sum of words 1 and 2, so a record of which only some dwords have
+    // landed is never accepted (soccer_hip.h, soccer_step_scalar)
+    auto byte_sum = [](uint32_t a, uint32_t b) { uint32_t s_ = 0; for (int q = 0; q < 4; ++q) s_ += ((a >> (8 * q)) & 0xffu) + ((b >> (8 * q)) & 0xffu); return s_ & 0xffu; };
+    auto landed = [&]() {
+        const uint32_t f0 = flag[0], f1 = flag[1], f2 = flag[2], f3 = flag[3];
+        return f0 == k.seq && (f3 >> 24) == (k.seq & 0xffu) && ((f3 >> 16) & 0xffu) == byte_sum(f1, f2);
+    };
     for (uint32_t spins = 0; !landed(); ++spins) {
         __builtin_ia32_pause();
         if ((spins & 0xfffffu) == 0xfffffu) {                            // every few ms: has the stream died?
@@ -1222,6 +1111,12 @@ extern "C" int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* mi
     return SOCCER_OK;
 }
 
+extern "C" uint32_t soccer_peek_misuse(const soccer_handle* h) {
+    if (!h || !h->misuse_host) return 0u;
+    const volatile unsigned int* m = h->misuse_host;
+    return (m[0] ? SOCCER_MISUSE_FROZEN : 0u) | (m[1] ? SOCCER_MISUSE_ACTION : 0u);
+}
+
 extern "C" int soccer_reset_stats(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1276,7 +1171,16 @@ extern "C" int soccer_timer_stop(soccer_handle* h, float* elapsed_ms) {
     if (!h || !elapsed_ms) return fail(h, SOCCER_E_INVALID, "handle/elapsed_ms is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    // poll instead of blocking: a blocked waiter is woken tens of microseconds after the event completes, which is
+    // as long as the whole timed region of a short run
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(h->ev1);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        if (spins > 2000u) { (void)hipGetLastError(); HIP_TRY(h, hipEventSynchronize(h->ev1)); break; }   // long waits: block
+        __builtin_ia32_pause();
+    }
+    (void)hipGetLastError();
     HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     return SOCCER_OK;
 }

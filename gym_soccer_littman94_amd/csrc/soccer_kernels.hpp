@@ -469,6 +469,17 @@ template <> struct PackB<1> {
     __device__ __forceinline__ void store_nt(void* base, unsigned long long i) const { store(base, i); }
 };
 
+// action bytes as the kernels execute them (swar::canon4); returns non-zero when a byte was outside 0..4
+template <int E> __device__ __forceinline__ uint32_t canon_pack(PackB<E>& a) {
+    uint32_t bad = 0u;
+    if constexpr (E == 1) { const uint32_t c = swar::canon4(a.b & 0xffu); bad = c ^ (a.b & 0xffu); a.b = c; }
+    else {
+#pragma unroll
+        for (int k = 0; k < PackB<E>::NW; ++k) { const uint32_t c = swar::canon4(a.w[k]); bad |= c ^ a.w[k]; a.w[k] = c; }
+    }
+    return bad;
+}
+
 // E consecutive uint16 of one stream, as E/2 dwords; values must already fit 16 bits
 template <int E> struct PackH {
     static constexpr int NW = E / 2;
@@ -689,6 +700,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
     if (stats) hist.init(P);
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
     bool mis = false;
+    uint32_t bad_act = 0u;
     for (unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; g < groups; g += stride) {
         const unsigned long long i0 = P.first + (g << 2);
         const int cnt = VEC ? 4 : ((P.n - (g << 2)) < 4ull ? (int)(P.n - (g << 2)) : 4);
@@ -699,6 +711,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
         uint32_t aa = 0u, ab = 0u;
         if (!EXPLICIT_U || !P.policy_a) aa = load4<VEC>(IO.act_a, i0, cnt);
         if (!EXPLICIT_U || !P.policy_b) ab = load4<VEC>(IO.act_b, i0, cnt);
+        // an action byte executes as table[byte & 7] with 5..7 -> NOOP, so none can index outside a rule table; any
+        // byte outside 0..4 is reported (the reference raises IndexError, :393)
+        { const uint32_t ca_ = swar::canon4(aa), cb_ = swar::canon4(ab); bad_act |= (ca_ ^ aa) | (cb_ ^ ab); aa = ca_; ab = cb_; }
         // randomness does not depend on the loads above: it is computed while they are in flight
         const bool need_philox = !EXPLICIT_U || (IO.u_step == nullptr) || (P.autoreset && IO.u_reset == nullptr);
         Philox4 blk{{0u, 0u, 0u, 0u}};
@@ -772,7 +787,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
                 if ((fin_mask >> j) & 1u) IO.last_return[i0 + j] = (int8_t)(o_rew >> (8 * j));
         }
     }
-    if (mis) *P.misuse = 1u;
+    if (mis) P.misuse[0] = 1u;
+    if (bad_act) P.misuse[1] = 1u;
     if (stats) hist.flush(P);
     if (P.tick_out) publish_tick(P, tick, 1ull);
 }
@@ -809,6 +825,9 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     if (!POLICY || !P.policy_a) aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
     if (!POLICY || !P.policy_b) ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
 #endif
+    // action bytes execute as table[byte & 7] with 5..7 -> NOOP; anything outside 0..4 is reported (:393)
+    const uint32_t aa_raw = aa, ab_raw = ab;
+    aa = swar::canon4(aa); ab = swar::canon4(ab);
     // The tick comes from device memory (graph replays cannot change kernel arguments).  It is read AFTER the
     // eight data loads above have been issued: read first, its scalar-cache miss (~1 us) sat in front of them.
     const unsigned long long tick = tick_ptr ? *tick_ptr : tick_val;
@@ -880,7 +899,8 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     if (IO.terminated) *reinterpret_cast<uint32_t*>(IO.terminated + i0) = o_term;
     if (IO.truncated) *reinterpret_cast<uint32_t*>(IO.truncated + i0) = o_trunc;
 #endif
-    if (mis) *P.misuse = 1u;
+    if (mis) P.misuse[0] = 1u;
+    if ((aa ^ aa_raw) | (ab ^ ab_raw)) P.misuse[1] = 1u;
 }
 
 // The seven leading scalar arguments (14 dwords) repeat the fields of P / IO that the first loads depend on
@@ -921,6 +941,8 @@ struct SwarParams {
     unsigned long long* tick_out;
     unsigned int* misuse;                   // [0] a frozen lane was stepped (:376), [1] an action byte outside 0..4 (:393)
     unsigned long long* hist;               // FULL: episode histogram slots (SOCCER_F_STEP_STATS), or nullptr
+    swar::SlipConsts L; const swar::Quad* sub;   // SLIP: scaled cumulative weights / the nine rows of quarter thresholds
+    const int8_t* policy_a; const int8_t* policy_b;   // POLICY: the fixed side's int8[nS] policy (the other is nullptr)
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs;
 };
@@ -930,7 +952,12 @@ struct SwarParams {
 // accesses measured best; 8 or 16 lanes per thread (dwordx2 / dwordx4), plain or write-through stores and 512-thread
 // workgroups were all equal or slower, and an instantiation without the frozen-lane / goal-tuple code was not faster
 // (the kernel is bound by launch + memory latency, not by vector issue any more).
-template <bool FULL>
+// SLIP: handles with slip_prob > 0 whose integer slip decision is exact for every draw (SlipTables::swar_ok): each lane
+// counts the scaled cumulative weights and its combination's quarter points below its draw (the threshold rows are
+// gathered while the state loads are still in flight: they depend on the random word only), the rest stays byte-parallel.
+// POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the observation of
+// the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
+template <bool FULL, bool SLIP = false, bool POLICY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
                                                            const unsigned long long* tick_in,
@@ -953,15 +980,27 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 3 * state_stride));
         S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 4 * state_stride));
         S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 5 * state_stride));
-        const uint32_t aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_a + i0));
-        const uint32_t ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_b + i0));
+        uint32_t aa = 0u, ab = 0u;
+        if (!POLICY || !Q.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_a + i0));
+        if (!POLICY || !Q.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_b + i0));
         // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
         const unsigned long long tick = tick_in ? *tick_in : tick_val;
         if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
         const unsigned long long q = (Q.lane_offset + i0) >> 2;     // the thread's 4 lanes are exactly one Philox block
         const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), Q.key0, Q.key1);
+        if (POLICY) {                                               // the fixed side acts on the current observation (:187-188)
+            uint32_t s_lo, s_hi;
+            const uint32_t cc0 = swar::bfi(swar::mask_of(S.ps << 7), S.cb, S.ca);
+            swar::obs4<true>(Q.C, S.ra, S.ca, S.rb, S.cb, S.ps & swar::K01, swar::is_zero(cc0) | swar::is_zero(cc0 ^ Q.C.Wm1x4), s_lo, s_hi);
+            const int8_t* pol = Q.policy_a ? Q.policy_a : Q.policy_b;
+            const uint32_t act = (uint32_t)(uint8_t)pol[s_lo & 0xffffu] | ((uint32_t)(uint8_t)pol[s_lo >> 16] << 8) |
+                                 ((uint32_t)(uint8_t)pol[s_hi & 0xffffu] << 16) | ((uint32_t)(uint8_t)pol[s_hi >> 16] << 24);
+            if (Q.policy_a) aa = act; else ab = act;
+        }
         swar::Out o;
-        swar::step4<true, FULL, false>(Q.C, S, aa, ab, 0u, 0u, 0u, 0u, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        uint32_t sa = 0u, sb = 0u, k4 = 0u, cls4 = 0u;
+        if (SLIP) swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+        swar::step4<true, FULL, SLIP>(Q.C, S, aa, ab, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
         uint8_t* sw = const_cast<uint8_t*>(sp);
         __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
         __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(sw + state_stride));
@@ -1030,7 +1069,8 @@ struct ScalarIO {
     uint32_t seq;       // written to record.x last
     double u_step, u_reset;
     uint4* record;      // host-mapped: { seq, obs | (reward & 0xff) << 16 | term << 24 | trunc << 25 | code << 26,
-                        //                next pos (as `pos`), poss | needs_reset << 1 | t << 8 | (seq & 0xffff) << 16 }
+                        //                next pos (as `pos`), poss | needs_reset << 1 | t << 8 | check << 16 | (seq & 0xff) << 24 }
+                        //                check = byte-sum of words 1 and 2 (a torn record is never taken for a complete one)
 };
 
 template <bool SLIP>
@@ -1064,10 +1104,13 @@ __global__ __launch_bounds__(64) void scalar_kernel(const KernelParams P, const 
     const uint32_t res = R.obs | (((uint32_t)R.reward & 0xffu) << 16) | (R.term << 24) | (R.trunc << 25) | (R.code << 26);
     const uint32_t npos = (L.A >> 24) | (((L.A >> 16) & 0xffu) << 8) | ((L.B >> 24) << 16) | (((L.B >> 16) & 0xffu) << 24);
     __threadfence_system();                 // the resident state before the record
-    // one 16-byte store = one write transaction; the sequence number opens it and its low half closes it, so the
-    // host can tell a complete record from a torn one without a second fence (a second fence would put a PCIe
+    // one 16-byte store = one write transaction; the sequence number opens it, its low byte closes it and word 3 carries a
+    // check byte over words 1 and 2, so the host can tell a complete record from a torn one without a second fence (a second fence would put a PCIe
     // round trip on the critical path: +1.6 us per step, measured)
-    *IO.record = make_uint4(IO.seq, res, npos, L.p | (L.need << 1) | (L.t << 8) | (IO.seq << 16));
+    uint32_t check = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) check += ((res >> (8 * q)) & 0xffu) + ((npos >> (8 * q)) & 0xffu);
+    *IO.record = make_uint4(IO.seq, res, npos, L.p | (L.need << 1) | (L.t << 8) | ((check & 0xffu) << 16) | (IO.seq << 24));
     // the call consumes one tick like every batched_* call; nothing above needed its value (the uniforms are the
     // caller's), so its cache miss stays off the path to the record
     *P.tick_out = *P.tick_in + 1ull;
@@ -1089,9 +1132,11 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
     for (int j = 0; j < E; ++j) { ret[j] = 0; eps[j] = 0; }
     PackB<E> aa, ab; aa.clear(); ab.clear();
     const bool sample = DYN && IO.sample_actions;
+    uint32_t bad_act = 0u;
     if (!sample) {
         if (!DYN || IO.act_a) aa.load_nt(IO.act_a, i0);
         if (!DYN || IO.act_b) ab.load_nt(IO.act_b, i0);
+        bad_act |= canon_pack(aa) | canon_pack(ab);
     }
     // the observation of the current tuple is carried along when an action depends on it
     const bool fixed = DYN && (P.policy_a != nullptr || P.policy_b != nullptr ||    // single-agent mode
@@ -1105,6 +1150,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         if (!sample && s + 1 < IO.n_steps) {                            // prefetch the next step's actions
             if (!DYN || IO.act_a) naa.load_nt(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
             if (!DYN || IO.act_b) nab.load_nt(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
+            bad_act |= canon_pack(naa) | canon_pack(nab);
         }
         uint32_t words[E], awords[E];
         lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
@@ -1154,6 +1200,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
     }
     if (IO.return_sum) add_words<E>(IO.return_sum, i0, ret);
     if (IO.episode_count) add_words<E>(IO.episode_count, i0, eps);
+    if (bad_act) P.misuse[1] = 1u;
 }
 
 template <int E, bool SLIP, bool LUT_LDS, bool DYN>
@@ -1175,292 +1222,171 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const KernelParams P, c
                 rollout_group<1, SLIP, DYN>(T, P, IO, i, tick0, hist, any_misuse);
         }
     }
-    if (any_misuse) *P.misuse = 1u;
+    if (any_misuse) P.misuse[0] = 1u;
     hist.flush(P);
 }
 
 // =================================================================================================
-// batched_rollout through an LDS-resident transition table (slip_prob == 0, tables that fit the LDS)
+// batched_rollout, byte-parallel: T fused steps with the four lanes of a thread packed in six registers
 // =================================================================================================
-// The rule-function rollout above is bound by vector-instruction issue (~110 per env-step).  Here the whole
-// (state, joint action) -> outcome relation of the pitch — what the reference materialises as P (:167-293),
-// 761 x 25 entries of 4 bytes = 76 KB for 5x4 — is staged once per workgroup into the CU's 160 KB LDS and a
-// lane carries its tuple as a STATE CODE: the observation index for live tuples, nS + goal id for goal
-// tuples.  A step is then one LDS gather plus ~20 selects.  Entry layout:
-//   bits 0-13 n0, bits 14-27 n1, bits 28-29 kind, bit 30 reward is +1 (else -1) when n0 is a goal code
-//   K_MOVE: next code n0 (goal code = scored)      K_FLIP: n0 = same cells, possession flipped
-//   K_COIN: n0 + k, k = possession drawn           K_FOUR: (k < 2 ? n0 : n1) + (k & 1)
-// (the p = 0 / p = 1 codes of one pair of cells are consecutive).  The table is built on the host from the
-// same classify() the kernels use (soccer_hip.hip, build_transition_table) and every rollout test runs
-// through it.
-struct TransTables {
-    const uint32_t* trans;        // [nS * 25]
-    const uint16_t* code_lut;     // [lut_len] tuple -> state code (0xFFFF unreachable)
-    const uint32_t* code_tuple;   // [n_codes] state code -> row_a | col_a << 4 | row_b << 8 | col_b << 12 | poss << 16
-    int32_t nS, n_codes;
-    int32_t mix_lds;              // the LDS has room for the two [nS][4] uint16 mixed-policy tables and the two
-                                  // int8[nS] fixed policies behind the table
+// The step of soccer_swar.hpp in a loop: no rule table, no LDS transition table (so every pitch that fits the byte
+// arithmetic — all golden ones up to 11x7 — and every slip whose integer decision is exact take the same kernel), no
+// state-code conversion on entry / exit, frozen and goal-tuple lanes handled by the step itself.  Per step a thread
+// issues one Philox block, two action dwords (prefetched a step ahead) and four result stores.
+//   DYN: some action is produced in the kernel — sampled uniformly or from [nS][4] mixed-policy thresholds (config 5),
+//        or looked up from a fixed int8[nS] policy (single-agent mode); these are per-lane gathers keyed by the lane's
+//        current observation, which the step already produces.  The tables sit in LDS when they fit (`lds_tables`).
+struct RolloutSwar {       // everything the kernel needs, and nothing else (KernelParams is twice this: SGPR spills)
+    uint8_t* state; unsigned long long state_stride;
+    unsigned long long first, n, lane_offset;
+    const unsigned long long* tick_in; unsigned long long* tick_out;
+    unsigned long long* hist; unsigned int* misuse;
+    const int8_t* policy_a; const int8_t* policy_b;
+    uint32_t key0, key1;
+    swar::Consts C; swar::SlipConsts L; const swar::Quad* sub;
+    int32_t nS; int32_t lds_tables;
 };
-constexpr int kTblBlock = 1024;          // one workgroup per CU shares one copy of the table
 
-// The T steps of one thread's E lanes.  GENERAL = false is the steady state of an auto-resetting handle: no
-// lane is frozen or sits in a goal tuple on entry, so none ever will, and the code for those cases (and the
-// per-lane return / episode accumulators, unless asked for) is compiled out; episode totals come from
-// population counts over the packed output dwords.
-// SLIP (handles with slip_int only): the draw first selects one of the nine slip combinations by counting the
-// scaled cumulative weights <= m, the table is read at the SLIPPED joint action (a slipped move is NOOP exactly
-// when the original action is, so the entry's NOOP tests are the reference's), and the outcome within the
-// combination by counting its scaled thresholds <= m (KernelParams::CB / sub, here `sub` in LDS).
-template <int E, bool DYN, bool GENERAL, bool SLIP>
-__device__ __forceinline__ void table_steps(const uint32_t* trans, const uint32_t* isd, const uint4* sub,
-                                            const uint2* mix_a, const uint2* mix_b,
-                                            const int8_t* pol_a, const int8_t* pol_b, uint32_t nS,
-                                            const KernelParams& P, const RolloutIO& IO,
-                                            unsigned long long i0, unsigned long long tick0,
-                                            uint32_t (&c)[E], uint32_t (&t)[E], uint32_t (&need)[E], int32_t (&acc)[E],
-                                            uint32_t& fin_tot, int32_t& rew_tot, uint32_t& nonzero, bool& any_misuse) {
-    const bool lane_acc = GENERAL || IO.return_sum != nullptr || IO.episode_count != nullptr;   // uniform
-    PackB<E> aa, ab; aa.clear(); ab.clear();
+// the T steps of one thread's four lanes.  GENERAL = false: no lane is frozen or in a goal tuple on entry and the handle
+// auto-resets, so none ever will be (the steady state): the step's code for those cases is compiled out.
+template <bool DYN, bool SLIP, bool GENERAL>
+__device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const swar::Quad* sub,
+                                                   const uint2* mix_a, const uint2* mix_b, const int8_t* pol_a, const int8_t* pol_b,
+                                                   unsigned long long i0, unsigned long long tick0, swar::Group& S,
+                                                   uint32_t& fin_tot, uint32_t& nz_tot, uint32_t& neg_tot,
+                                                   uint32_t (&acc)[4], uint32_t& frozen_any, uint32_t& bad_any) {
     const bool sample = DYN && IO.sample_actions;
+    const bool lane_acc = IO.return_sum != nullptr || IO.episode_count != nullptr;
+    const bool by_obs = DYN && (pol_a != nullptr || pol_b != nullptr || (sample && (mix_a != nullptr || mix_b != nullptr)));
+    uint32_t aa = 0u, ab = 0u;
     if (!sample) {
-        if (!DYN || IO.act_a) aa.load_nt(IO.act_a, i0);
-        if (!DYN || IO.act_b) ab.load_nt(IO.act_b, i0);
+        if (!DYN || IO.act_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
+        if (!DYN || IO.act_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
     }
+    // the observation of the current tuple (goal tuples: 0), carried along when an action depends on it
+    uint32_t s_lo = 0u, s_hi = 0u;
+    if (by_obs) {
+        const uint32_t cc0 = swar::bfi(swar::mask_of(S.ps << 7), S.cb, S.ca);
+        swar::obs4<true>(R.C, S.ra, S.ca, S.rb, S.cb, S.ps & swar::K01, swar::is_zero(cc0) | swar::is_zero(cc0 ^ R.C.Wm1x4), s_lo, s_hi);
+    }
+    const unsigned long long q = (R.lane_offset + i0) >> 2;
     for (int s = 0; s < IO.n_steps; ++s) {
         const unsigned long long tick = tick0 + (unsigned long long)s;
-        PackB<E> naa = aa, nab = ab;
+        uint32_t naa = aa, nab = ab;
         if (!sample && s + 1 < IO.n_steps) {                            // prefetch the next step's actions
-            if (!DYN || IO.act_a) naa.load_nt(IO.act_a + (long long)(s + 1) * IO.act_stride, i0);
-            if (!DYN || IO.act_b) nab.load_nt(IO.act_b + (long long)(s + 1) * IO.act_stride, i0);
+            if (!DYN || IO.act_a) naa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)(s + 1) * IO.act_stride + i0));
+            if (!DYN || IO.act_b) nab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)(s + 1) * IO.act_stride + i0));
         }
-        uint32_t words[E], awords[E];
-        lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
-        if (sample) lane_words<E>(P, P.lane_offset + i0, tick, 1u, awords);
-        PackB<E> o_rew, o_term, o_trunc; PackH<E> o_obs;
-        o_rew.clear(); o_term.clear(); o_trunc.clear(); o_obs.clear();
+        const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
+        uint32_t a4 = aa, b4 = ab;
+        if (DYN) {
+            uint32_t aw[4] = {0u, 0u, 0u, 0u};
+            if (sample) {
+                const Philox4 ab_blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32) | 0x80000000u, R.key0, R.key1);
+                aw[0] = ab_blk.w[0]; aw[1] = ab_blk.w[1]; aw[2] = ab_blk.w[2]; aw[3] = ab_blk.w[3];
+                a4 = 0u; b4 = 0u;
+            }
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const uint32_t top2 = words[j] >> 30, reset2 = words[j] & 3u;
-            const uint32_t cj = c[j], tj = t[j];
-            const bool in_goal = GENERAL && cj >= nS;
-            const uint32_t s_now = in_goal ? 0u : cj;                   // the current observation
-            uint32_t a = aa.get(j), b = ab.get(j);
-            if (sample) {                               // two actions from one 32-bit word, 15 bits each
-                const uint32_t ha = awords[j] & 0x7fffu, hb = (awords[j] >> 16) & 0x7fffu;
-                a = (ha * 5u) >> 15;
-                b = (hb * 5u) >> 15;
-                if (mix_a) {
-                    const uint2 th = mix_a[s_now];
-                    a = (ha >= (th.x & 0xffffu)) + (ha >= (th.x >> 16)) + (ha >= (th.y & 0xffffu)) + (ha >= (th.y >> 16));
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ob = ((j & 2 ? s_hi : s_lo) >> (16 * (j & 1))) & 0xffffu;
+                if (sample) {                       // two actions from one 32-bit word, 15 bits each
+                    const uint32_t ha = aw[j] & 0x7fffu, hb = (aw[j] >> 16) & 0x7fffu;
+                    uint32_t a = (ha * 5u) >> 15, b = (hb * 5u) >> 15;          // uniform
+                    if (mix_a) { const uint2 th = mix_a[ob];
+                                 a = (ha >= (th.x & 0xffffu)) + (ha >= (th.x >> 16)) + (ha >= (th.y & 0xffffu)) + (ha >= (th.y >> 16)); }
+                    if (mix_b) { const uint2 th = mix_b[ob];
+                                 b = (hb >= (th.x & 0xffffu)) + (hb >= (th.x >> 16)) + (hb >= (th.y & 0xffffu)) + (hb >= (th.y >> 16)); }
+                    a4 |= a << (8 * j); b4 |= b << (8 * j);
                 }
-                if (mix_b) {
-                    const uint2 th = mix_b[s_now];
-                    b = (hb >= (th.x & 0xffffu)) + (hb >= (th.x >> 16)) + (hb >= (th.y & 0xffffu)) + (hb >= (th.y >> 16));
-                }
-            }
-            if (DYN) {
-                if (pol_a) a = (uint32_t)(uint8_t)pol_a[s_now];
-                if (pol_b) b = (uint32_t)(uint8_t)pol_b[s_now];
-            }
-            uint32_t e, kind, k;
-            if (SLIP) {
-                const uint32_t m = words[j] >> 2;
-                uint32_t idx = 0u;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) idx += m >= P.CB[i] ? 1u : 0u;
-                const uint32_t c_i = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull);
-                constexpr uint32_t VA2 = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);
-                constexpr uint32_t VB2 = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (2u << 12) | (1u << 14) | (2u << 16);
-                const uint32_t va = (VA2 >> (2u * c_i)) & 3u, vb = (VB2 >> (2u * c_i)) & 3u;
-                // slip_move: NOOP->NOOP,NOOP  NORTH->EAST,WEST  SOUTH->WEST,EAST  EAST->SOUTH,NORTH  WEST->NORTH,SOUTH
-                const uint32_t a1 = (0x12430u >> (4u * a)) & 7u, a2 = (0x21340u >> (4u * a)) & 7u;
-                const uint32_t b1 = (0x12430u >> (4u * b)) & 7u, b2 = (0x21340u >> (4u * b)) & 7u;
-                const uint32_t as = va == 0u ? a : (va == 1u ? a1 : a2), bs = vb == 0u ? b : (vb == 1u ? b1 : b2);
-                e = trans[mad24(s_now, 25u, mad24(as, 5u, bs))];
-                kind = (e >> 28) & 3u;
-                const uint4 th = sub[idx];
-                const bool two = kind == K_COIN, four = kind == K_FOUR;
-                k = (((two & (m >= th.x)) | (four & (m >= th.y))) ? 1u : 0u) + ((four & (m >= th.z)) ? 1u : 0u) +
-                    ((four & (m >= th.w)) ? 1u : 0u);
-            } else {
-                e = trans[mad24(s_now, 25u, mad24(a, 5u, b))];
-                kind = (e >> 28) & 3u;
-                k = kind == K_COIN ? (top2 >> 1) : top2;                // floor(2u) / floor(4u), as lane_step
-            }
-            const bool second = (kind == K_FOUR) & (k >= 2u);
-            const uint32_t base = second ? ((e >> 14) & 0x3fffu) : (e & 0x3fffu);
-            uint32_t nc = base + (kind >= K_COIN ? (k & 1u) : 0u);
-            if (GENERAL) nc = in_goal ? cj : nc;                        // goal tuples are absorbing (:300-301)
-            const bool goal_now = nc >= nS;
-            const int32_t reward = (goal_now & !in_goal) ? ((e >> 30) & 1u ? 1 : -1) : 0;
-            const uint32_t tt = tj + 1u;
-            const uint32_t trunc = tt >= (uint32_t)P.max_steps ? 1u : 0u;
-            const uint32_t done = goal_now ? 1u : 0u;
-            const uint32_t nd = done | trunc;
-            uint32_t ob = goal_now ? 0u : nc;
-            uint32_t c2 = nc, t2 = tt, need2 = nd;
-            if (!GENERAL || P.autoreset) {                              // uniform
-                const uint32_t z = isd[4u * (reset2 >> P.isd_shift) + 2u] >> 16;    // ISD entry's observation = its code
-                c2 = nd ? z : nc; t2 = nd ? 0u : tt; need2 = 0u; ob = c2;
-            }
-            if (GENERAL) {
-                const bool frozen = need[j] != 0u;                      // left untouched (:376)
-                any_misuse |= frozen;
-                const uint32_t r_obs = frozen ? s_now : ob;
-                const int32_t r_rew = frozen ? 0 : reward;
-                const uint32_t r_term = frozen ? (in_goal ? 1u : 0u) : done;
-                const uint32_t r_trunc = frozen ? (tj >= (uint32_t)P.max_steps ? 1u : 0u) : trunc;
-                const uint32_t fin = frozen ? 0u : nd;
-                c[j] = frozen ? cj : c2; t[j] = frozen ? tj : t2; need[j] = frozen ? 1u : need2;
-                o_obs.put(j, r_obs); o_rew.put(j, (uint32_t)r_rew & 0xffu); o_term.put(j, r_term); o_trunc.put(j, r_trunc);
-                acc[j] += (r_rew << 16) + (int32_t)fin; nonzero += (uint32_t)r_rew & 1u;
-                fin_tot += fin; rew_tot += r_rew;
-            } else {
-                c[j] = c2; t[j] = t2;
-                o_obs.put(j, ob); o_rew.put(j, (uint32_t)reward & 0xffu); o_term.put(j, done); o_trunc.put(j, trunc);
-                if (lane_acc) acc[j] += (reward << 16) + (int32_t)nd;
+                if (pol_a) a4 = (a4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_a[ob] << (8 * j));
+                if (pol_b) b4 = (b4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_b[ob] << (8 * j));
             }
         }
-        if (!GENERAL) {                     // totals of the E lanes from the packed bytes (0/1 flags, rewards 0x00/0x01/0xff)
-            if constexpr (E == 1) {
-                fin_tot += o_term.b | o_trunc.b; nonzero += o_rew.b & 1u; rew_tot += (int32_t)(int8_t)o_rew.b;
-            } else {
-#pragma unroll
-                for (int q = 0; q < E / 4; ++q) {
-                    const uint32_t nz = __builtin_popcount(o_rew.w[q] & 0x01010101u), ng = __builtin_popcount(o_rew.w[q] & 0x80808080u);
-                    fin_tot += __builtin_popcount((o_term.w[q] | o_trunc.w[q]) & 0x01010101u);
-                    nonzero += nz; rew_tot += (int32_t)nz - 2 * (int32_t)ng;
-                }
-            }
+        swar::Out o;
+        uint32_t sa = 0u, sb = 0u, k4 = 0u, cls4 = 0u;
+        if (SLIP) swar::slip_select4(R.L, sub, swar::canon4(a4), swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+        swar::step4<GENERAL, false, SLIP>(R.C, S, a4, b4, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        s_lo = o.obs_lo; s_hi = o.obs_hi;
+        const long long off = (long long)s * IO.out_stride + (long long)i0;
+        if (IO.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
+                                                reinterpret_cast<unsigned long long*>(IO.obs + off));
+        if (IO.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(IO.reward + off));
+        if (IO.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(IO.terminated + off));
+        if (IO.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(IO.truncated + off));
+        // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends an episode
+        fin_tot += (uint32_t)__builtin_popcount(o.finished & swar::K80);
+        nz_tot += (uint32_t)__builtin_popcount(o.rew & swar::K01); neg_tot += (uint32_t)__builtin_popcount(o.rew & swar::K80);
+        if (lane_acc) {                                             // wave-uniform
+            // reward bytes sign-extended to int16 pairs (v_perm_b32's sign selectors), finished flags to 0 / 1
+            acc[0] = swar::pk_add(acc[0], swar::perm(o.rew << 8, o.rew, 0x08010a00u));
+            acc[1] = swar::pk_add(acc[1], swar::perm(o.rew << 8, o.rew, 0x09030b02u));
+            const uint32_t f01 = swar::one_of(o.finished);
+            acc[2] += swar::perm(0u, f01, 0x0c010c00u); acc[3] += swar::perm(0u, f01, 0x0c030c02u);   // <= 4096 < 2^16: no carry
         }
-        const long long off = (long long)s * IO.out_stride;
-        if (IO.obs) o_obs.store_nt(IO.obs + off, i0);
-        if (IO.reward) o_rew.store_nt(IO.reward + off, i0);
-        if (IO.terminated) o_term.store_nt(IO.terminated + off, i0);
-        if (IO.truncated) o_trunc.store_nt(IO.truncated + off, i0);
+        if (GENERAL) frozen_any |= o.frozen;
+        bad_any |= o.bad_action;
         aa = naa; ab = nab;
     }
 }
 
-template <int E, bool DYN, bool SLIP>
-__device__ __forceinline__ void rollout_table_group(const uint32_t* trans, const uint32_t* isd, const uint4* sub,
-                                                    const uint2* mix_a, const uint2* mix_b,
-                                                    const int8_t* pol_a, const int8_t* pol_b, const TransTables& TT,
-                                                    const KernelParams& P, const RolloutIO& IO,
-                                                    unsigned long long i0, unsigned long long tick0,
-                                                    HistAcc<false>& hist, bool& any_misuse) {
-    const uint32_t nS = (uint32_t)TT.nS;
-    uint32_t c[E], t[E], need[E];
-    uint32_t frozen_mask = 0u;
-    bool special = P.autoreset == 0u;       // any lane frozen or in a goal tuple on entry, or no auto-reset
-    {
-        RawState<E> raw; raw.load(P, i0);
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const uint32_t f = (mad24(mad24(raw.ra.get(j), (uint32_t)P.W, raw.ca.get(j)), (uint32_t)P.HW,
-                                      mad24(raw.rb.get(j), (uint32_t)P.W, raw.cb.get(j))) << 1) | (raw.ps.get(j) & 1u);
-            const uint32_t code = TT.code_lut[f];
-            const bool bad = code >= (uint32_t)TT.n_codes;              // unreachable tuple written behind the API's back
-            c[j] = bad ? 0u : code; t[j] = raw.tt.get(j);
-            need[j] = bad ? 1u : ((raw.ps.get(j) >> 1) & 1u);
-            frozen_mask |= need[j] << j;
-            special |= (need[j] != 0u) | (c[j] >= nS);
-        }
-    }
-    int32_t acc[E];                         // per lane: return << 16 (signed) + finished episodes (a launch has <= 4096 steps)
-    uint32_t nonzero = 0u, fin_tot = 0u; int32_t rew_tot = 0;
-#pragma unroll
-    for (int j = 0; j < E; ++j) acc[j] = 0;
-    if (special) table_steps<E, DYN, true, SLIP>(trans, isd, sub, mix_a, mix_b, pol_a, pol_b, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
-    else table_steps<E, DYN, false, SLIP>(trans, isd, sub, mix_a, mix_b, pol_a, pol_b, nS, P, IO, i0, tick0, c, t, need, acc, fin_tot, rew_tot, nonzero, any_misuse);
-    {   // codes back to tuples; lanes that were frozen on entry keep their bytes (rare: re-read them)
-        PackB<E> ra, ca, rb, cb, ps, tt;
-        ra.clear(); ca.clear(); rb.clear(); cb.clear(); ps.clear(); tt.clear();
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const uint32_t tup = TT.code_tuple[c[j]];
-            ra.put(j, tup & 15u); ca.put(j, (tup >> 4) & 15u); rb.put(j, (tup >> 8) & 15u); cb.put(j, (tup >> 12) & 15u);
-            ps.put(j, ((tup >> 16) & 1u) | (need[j] << 1)); tt.put(j, t[j]);
-        }
-        if (frozen_mask) {
-            RawState<E> raw; raw.load(P, i0);
-            if constexpr (E == 1) {
-                ra.b = raw.ra.b; ca.b = raw.ca.b; rb.b = raw.rb.b; cb.b = raw.cb.b; ps.b = raw.ps.b; tt.b = raw.tt.b;
-            } else {
-                static_assert(E == 1 || E == 4, "the table rollout packs 4 lanes per dword");
-                uint32_t m = 0u;                                        // byte mask of the frozen lanes
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m |= ((frozen_mask >> j) & 1u) ? (0xffu << (8 * j)) : 0u;
-                ra.w[0] = (ra.w[0] & ~m) | (raw.ra.w[0] & m); ca.w[0] = (ca.w[0] & ~m) | (raw.ca.w[0] & m);
-                rb.w[0] = (rb.w[0] & ~m) | (raw.rb.w[0] & m); cb.w[0] = (cb.w[0] & ~m) | (raw.cb.w[0] & m);
-                ps.w[0] = (ps.w[0] & ~m) | (raw.ps.w[0] & m); tt.w[0] = (tt.w[0] & ~m) | (raw.tt.w[0] & m);
-            }
-        }
-        uint8_t* sp = P.state;
-        ra.store(sp, i0); ca.store(sp + P.state_stride, i0); rb.store(sp + 2 * P.state_stride, i0);
-        cb.store(sp + 3 * P.state_stride, i0); ps.store(sp + 4 * P.state_stride, i0); tt.store(sp + 5 * P.state_stride, i0);
-    }
-    hist.add_totals(fin_tot, rew_tot, nonzero);
-    if (IO.return_sum || IO.episode_count) {
-        int32_t ret[E], eps[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) { eps[j] = acc[j] & 0xffff; ret[j] = (acc[j] - eps[j]) >> 16; }   // finished <= 4096 < 2^16
-        if (IO.return_sum) add_words<E>(IO.return_sum, i0, ret);
-        if (IO.episode_count) add_words<E>(IO.episode_count, i0, eps);
-    }
-}
-
-constexpr int kTblHead = kIsdWords + 36;     // LDS words ahead of the table: ISD entries, then the 9 x 4 slip thresholds
-
-template <int E, bool DYN, bool SLIP>
-__global__ __launch_bounds__(kTblBlock) void rollout_table_kernel(const KernelParams P, const RolloutIO IO, const TransTables TT) {
+template <bool DYN, bool SLIP>
+__global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar R, const RolloutIO IO) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    HistAcc<false> hist; hist.init(P);
-    if (threadIdx.x < kIsdWords) smem[threadIdx.x] = P.isd[threadIdx.x];
-    if (SLIP && threadIdx.x < 36) smem[kIsdWords + threadIdx.x] = reinterpret_cast<const uint32_t*>(P.sub)[threadIdx.x];
-    uint32_t* trans = smem + kTblHead;
-    {
-        const int n4 = (TT.nS * 25) >> 2;                               // nS * 25 words, copied as dwordx4 + tail
-        const uint4* src = reinterpret_cast<const uint4*>(TT.trans);
-        uint4* dst = reinterpret_cast<uint4*>(trans);
-        for (int i = threadIdx.x; i < n4; i += kTblBlock) dst[i] = src[i];
-        for (int i = (n4 << 2) + threadIdx.x; i < TT.nS * 25; i += kTblBlock) trans[i] = TT.trans[i];
-    }
-    // mixed-policy thresholds (config 5): one 8-byte row per state and player, behind the table when there is room
+    HistAcc<false> hist; hist.init_at(R.hist);
+    // LDS: [0, 36) the nine threshold rows (SLIP), then (DYN, when they fit) mix_a, mix_b rows (8 B per state) and the
+    // two fixed policies (1 B per state)
+    const swar::Quad* sub = R.sub;
     const uint2* mix_a = reinterpret_cast<const uint2*>(IO.mix_a);
     const uint2* mix_b = reinterpret_cast<const uint2*>(IO.mix_b);
-    if (DYN && TT.mix_lds && IO.sample_actions) {
-        uint2* la = reinterpret_cast<uint2*>(trans + ((TT.nS * 25 + 3) & ~3));
-        uint2* lb = la + TT.nS;
-        if (mix_a) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) la[i] = mix_a[i]; mix_a = la; }
-        if (mix_b) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) lb[i] = mix_b[i]; mix_b = lb; }
+    const int8_t* pol_a = R.policy_a; const int8_t* pol_b = R.policy_b;
+    const bool sample = DYN && IO.sample_actions;
+    if (SLIP || (DYN && R.lds_tables)) {
+        if (SLIP) { if (threadIdx.x < 36) smem[threadIdx.x] = reinterpret_cast<const uint32_t*>(R.sub)[threadIdx.x];
+                    sub = reinterpret_cast<const swar::Quad*>(smem); }
+        if (DYN && R.lds_tables) {
+            uint2* la = reinterpret_cast<uint2*>(smem + 36); uint2* lb = la + R.nS;
+            int8_t* pa = reinterpret_cast<int8_t*>(lb + R.nS); int8_t* pb = pa + ((R.nS + 15) & ~15);
+            if (sample && mix_a) { for (int i = threadIdx.x; i < R.nS; i += kBlock) la[i] = mix_a[i]; mix_a = la; }
+            if (sample && mix_b) { for (int i = threadIdx.x; i < R.nS; i += kBlock) lb[i] = mix_b[i]; mix_b = lb; }
+            if (pol_a) { for (int i = threadIdx.x; i < R.nS; i += kBlock) pa[i] = pol_a[i]; pol_a = pa; }
+            if (pol_b) { for (int i = threadIdx.x; i < R.nS; i += kBlock) pb[i] = pol_b[i]; pol_b = pb; }
+        }
+        __syncthreads();
     }
-    // fixed policies of single-agent mode (int8[nS]), behind the mixed-policy rows
-    const int8_t* pol_a = P.policy_a; const int8_t* pol_b = P.policy_b;
-    if (DYN && TT.mix_lds) {
-        int8_t* la = reinterpret_cast<int8_t*>(trans + ((TT.nS * 25 + 3) & ~3) + 4 * TT.nS);
-        int8_t* lb = la + ((TT.nS + 15) & ~15);
-        if (pol_a) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) la[i] = pol_a[i]; pol_a = la; }
-        if (pol_b) { for (int i = threadIdx.x; i < TT.nS; i += kTblBlock) lb[i] = pol_b[i]; pol_b = lb; }
-    }
-    __syncthreads();
-    const uint4* sub = reinterpret_cast<const uint4*>(smem + kIsdWords);
-    const unsigned long long tick0 = *P.tick_in;
-    publish_tick(P, tick0, (unsigned long long)IO.n_steps);
-    const unsigned long long groups = (P.n + E - 1) / E;
-    bool any_misuse = false;
-    for (unsigned long long g = (unsigned long long)blockIdx.x * kTblBlock + threadIdx.x; g < groups;
-         g += (unsigned long long)gridDim.x * kTblBlock) {
-        const unsigned long long i0 = g * E;
-        if (E == 1 || i0 + E <= P.n) {
-            rollout_table_group<E, DYN, SLIP>(trans, smem, sub, mix_a, mix_b, pol_a, pol_b, TT, P, IO, i0, tick0, hist, any_misuse);
-        } else {
-            for (unsigned long long i = i0; i < P.n; ++i)
-                rollout_table_group<1, DYN, SLIP>(trans, smem, sub, mix_a, mix_b, pol_a, pol_b, TT, P, IO, i, tick0, hist, any_misuse);
+    const unsigned long long tick0 = *R.tick_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *R.tick_out = tick0 + (unsigned long long)IO.n_steps;
+    const unsigned long long groups = R.n >> 2;                      // the launch covers a multiple of 4 lanes
+    uint32_t frozen_any = 0u, bad_any = 0u;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; g < groups;
+         g += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long i0 = R.first + (g << 2);
+        const uint8_t* sp = R.state + i0;
+        swar::Group S;
+        S.ra = *reinterpret_cast<const uint32_t*>(sp); S.ca = *reinterpret_cast<const uint32_t*>(sp + R.state_stride);
+        S.rb = *reinterpret_cast<const uint32_t*>(sp + 2 * R.state_stride); S.cb = *reinterpret_cast<const uint32_t*>(sp + 3 * R.state_stride);
+        S.ps = *reinterpret_cast<const uint32_t*>(sp + 4 * R.state_stride); S.tt = *reinterpret_cast<const uint32_t*>(sp + 5 * R.state_stride);
+        uint32_t fin_tot = 0u, nz_tot = 0u, neg_tot = 0u;
+        uint32_t acc[4] = {0u, 0u, 0u, 0u};     // per lane: int16 return (two pairs), uint16 finished episodes (two pairs); T <= 4096
+        // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
+        const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
+        const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
+        if (special) rollout_swar_group<DYN, SLIP, true>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYN, SLIP, false>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        uint8_t* sw = R.state + i0;
+        *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
+        *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;
+        *reinterpret_cast<uint32_t*>(sw + 4 * R.state_stride) = S.ps; *reinterpret_cast<uint32_t*>(sw + 5 * R.state_stride) = S.tt;
+        hist.add_totals(fin_tot, (int32_t)nz_tot - 2 * (int32_t)neg_tot, nz_tot);
+        if (IO.return_sum != nullptr || IO.episode_count != nullptr) {
+            int32_t ret[4] = {(int32_t)(int16_t)(acc[0] & 0xffffu), (int32_t)(int16_t)(acc[0] >> 16), (int32_t)(int16_t)(acc[1] & 0xffffu), (int32_t)(int16_t)(acc[1] >> 16)};
+            int32_t eps[4] = {(int32_t)(acc[2] & 0xffffu), (int32_t)(acc[2] >> 16), (int32_t)(acc[3] & 0xffffu), (int32_t)(acc[3] >> 16)};
+            if (IO.return_sum) add_words<4>(IO.return_sum, i0, ret);
+            if (IO.episode_count) add_words<4>(IO.episode_count, i0, eps);
         }
     }
-    if (any_misuse) *P.misuse = 1u;
-    hist.flush(P);
+    if (frozen_any) R.misuse[0] = 1u;
+    if (bad_any) R.misuse[1] = 1u;
+    hist.flush_at(R.hist);
 }
 
 // =================================================================================================

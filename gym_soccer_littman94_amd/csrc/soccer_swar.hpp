@@ -71,6 +71,17 @@ SOCCER_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// v_pk_add_u16: a + b on the two 16-bit halves, wrapping
+SOCCER_HD uint32_t pk_add(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, r);
+#else
+    return ((a + b) & 0xffffu) | ((((a >> 16) + (b >> 16)) & 0xffffu) << 16);
+#endif
+}
+
 constexpr uint32_t K80 = 0x80808080u, K01 = 0x01010101u, K7F = 0x7f7f7f7fu;
 
 // flag word (truth in bit 7 of each byte) -> byte mask 0xff / 0x00: the sign selectors of v_perm_b32 reach the odd
@@ -172,6 +183,49 @@ SOCCER_HD void move4(const Consts& C, uint32_t r, uint32_t c, uint32_t mv, uint3
     nc = bfi(mask_of(revert), c, ct);
 }
 
+// ---- slip: which of the nine combinations a lane's draw selects, and where in it the draw falls -------------------
+// (:202-227, :241, :395) for draws that come from a Philox word, u = m * 2^-30 with m = w >> 2: the integer form of the
+// first-exceeds rule over the list's running sums (soccer_slip.hpp builds and checks the scaled thresholds).
+struct alignas(16) Quad { uint32_t x, y, z, w; };    // per combination: scaled { mid-point, quarter points 1, 2, 3 } of its mass
+struct SlipConsts {
+    uint32_t CB[9];        // scaled cumulative weight after each active combination (0xFFFFFFFF beyond)
+    uint32_t c_off;        // id of the first active combination (0; 5 when slip_prob == 1)
+};
+// combination tables indexed by 8 - id (so that id 0 lands on v_perm_b32's "sign of byte 1" selector, which yields 0):
+// A's / B's move variant (0 intended, 1 / 2 the orthogonals) and the weight class, for ids 8 .. 1
+constexpr uint32_t T_VA_LO = 0x01010202u, T_VA_HI = 0x00000102u;
+constexpr uint32_t T_VB_LO = 0x01020102u, T_VB_HI = 0x01020000u;
+constexpr uint32_t T_CL_LO = 0x03030303u, T_CL_HI = 0x01010202u;
+
+// aa / ab: canonical actions (canon4).  sub: the 9 threshold rows (global or LDS).  Per lane: combination = number of
+// scaled cumulative weights <= m; quarter = number of that combination's quarter points <= m.  The rest is byte-parallel.
+SOCCER_HD void slip_select4(const SlipConsts& L, const Quad* sub, uint32_t aa, uint32_t ab,
+                            uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                            uint32_t& sa, uint32_t& sb, uint32_t& k4, uint32_t& cls4) {
+    const uint32_t w[4] = {w0, w1, w2, w3};
+    uint32_t c4 = 0u; k4 = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t m = w[j] >> 2;
+        uint32_t idx = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 9; ++i) idx += m >= L.CB[i] ? 1u : 0u;
+        const Quad th = sub[idx];
+        const uint32_t q = (m >= th.y ? 1u : 0u) + (m >= th.z ? 1u : 0u) + (m >= th.w ? 1u : 0u);
+        c4 |= (idx + L.c_off) << (8 * j); k4 |= q << (8 * j);
+    }
+    const uint32_t sel = 0x08080808u - c4;
+    const uint32_t va = perm(T_VA_HI, T_VA_LO, sel), vb = perm(T_VB_HI, T_VB_LO, sel);
+    cls4 = perm(T_CL_HI, T_CL_LO, sel);
+    // slipped move: variant 0 the action itself, 1 / 2 its orthogonals (:205-206)
+    sa = bfi(perm(0u, 0x0000ff00u, va), perm(T_SLIP1_HI, T_SLIP1_LO, aa), bfi(perm(0u, 0x00ff0000u, va), perm(T_SLIP2_HI, T_SLIP2_LO, aa), aa));
+    sb = bfi(perm(0u, 0x0000ff00u, vb), perm(T_SLIP1_HI, T_SLIP1_LO, ab), bfi(perm(0u, 0x00ff0000u, vb), perm(T_SLIP2_HI, T_SLIP2_LO, ab), ab));
+}
+
 // Observation index of four tuples (ra, ca, rb, cb, p): 1 + 2 * (iA * (NI - 1) + iB - (iB > iA)) + p over interior-cell
 // indices i = row * (W - 2) + col - 1 = cell - 2 * row - 1 (Rules::build checks the table against this closed form of
 // the reference's enumeration order, :63-109), evaluated as iA * 2(NI - 1) + (2 * (iB - gt) + 1 + p) on two 16-bit
@@ -195,9 +249,12 @@ SOCCER_HD void obs4(const Consts& C, uint32_t r_a, uint32_t c_a, uint32_t r_b, u
 // GENERAL = false: the steady state of an auto-resetting handle — no lane is frozen or stands in a goal tuple on
 //   entry (so none ever will): the code for those cases is compiled out.  The host tracks when that holds.
 // FULL: also produce final_obs and prob_code (VectorSoccerEnv's info / final_observation).
-// SLIP: `sa` / `sb` are the slipped moves of the combination the caller selected per lane and `k4` (bytes 0..3) the
-//   outcome index within it; otherwise the moves are the actions and the outcome index comes from the top two bits of
-//   each lane's random word (slip_prob == 0: list probabilities are 1, .5/.5 or .25 x 4).
+// SLIP: `sa` / `sb` are the slipped moves of the combination the caller selected per lane (slip_select4) and `k4`
+//   (one byte per lane) the QUARTER of that combination's probability mass the draw fell into: the outcome index of a
+//   four-way list, and twice the outcome index of a two-way list (the host checks that the scaled mid-point threshold
+//   of a combination equals its second quarter threshold); `cls4` its weight class for prob_code.  Otherwise the moves
+//   are the actions and the quarter is the top two bits of each lane's random word (slip_prob == 0: list
+//   probabilities are 1, .5/.5 or .25 x 4, i.e. floor(2u) / floor(4u)).
 // w0..w3: the lanes' random words (u = (w >> 2) * 2^-30, reset draw = w & 3).
 template <bool GENERAL, bool FULL, bool SLIP>
 SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw, uint32_t sa, uint32_t sb, uint32_t k4,
@@ -247,7 +304,7 @@ SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw
         const uint32_t T4 = perm(x23, x01, 0x05040100u);                   // byte j = top byte of lane j's word
         kb1 = T4; kb0c = T4; kb0f = T4 << 1;                               // floor(2u) / floor(4u): bits 31 and 30
     } else {
-        kb1 = k4 << 6; kb0c = k4 << 7; kb0f = kb0c;                        // k in 0..1 (coin) or 0..3 (four)
+        kb1 = k4 << 6; kb0c = kb1; kb0f = k4 << 7;                         // quarter 0..3: bit 1 / bit 1 / bit 0
     }
     const uint32_t amv = (four & kb1) | mv;                                // A takes its cell: k >= 2 of a four-way tie
     const uint32_t bmv = bfi(kb1, mv, four | mv);                          // B takes its cell: k < 2

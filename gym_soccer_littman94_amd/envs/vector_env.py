@@ -225,8 +225,12 @@ class VectorSoccerEnv:
         for x in (a, bb):
             assert x is None or (x.dtype == t.int8 and x.is_cuda and x.shape == (n,) and x.is_contiguous()), \
                 "device io expects contiguous torch.int8 CUDA tensors"
-        # action VALUES are not read back on this path: a byte outside 0..4 executes as NOOP-or-(value & 7) inside the
-        # pitch (never an out-of-table access) and raises the sticky misuse flag (`self.batch.misuse() & 2`)
+        # Action VALUES cannot be asserted here without a device round trip.  The kernels execute a byte b as the move
+        # table[b & 7] with 5..7 = NOOP (never an out-of-table access) and raise a sticky flag for any byte outside 0..4;
+        # strict mode looks at the flags of the launches completed so far (a host-mapped word, no synchronisation), so a
+        # bad action or a step on finished lanes surfaces as the reference's AssertionError one or two steps late.
+        if self.strict and b.peek_misuse():
+            self._raise_on_misuse()
         args = self._step_args
         args.act_a = a.data_ptr() if a is not None else None
         args.act_b = bb.data_ptr() if bb is not None else None
@@ -240,8 +244,12 @@ class VectorSoccerEnv:
         return self._rew
 
     def _raise_on_misuse(self):
-        if self._batch.misuse():
+        flags = self._batch.misuse()
+        if flags:
             self._batch.reset_stats()
+            if flags & SoccerBatch.MISUSE_ACTION:
+                raise AssertionError("actions must be in 0..4 (an action byte outside that range reached the device; "
+                                     "it was executed as a move inside the pitch)")
             raise AssertionError("Please reset the environment before taking a step "
                                  "(some lanes had terminated or truncated; they were left untouched)")
 

@@ -98,7 +98,12 @@ typedef struct soccer_config {
 } soccer_config;
 
 /* batched_step_ex arguments.  Required: act_a, act_b (each unless that player has a fixed policy).
- * Every output may be NULL (skipped). */
+ * Every output may be NULL (skipped).
+ * Action bytes: 0..4.  The *_host / *_staged entry points check every byte on the CPU and return
+ * SOCCER_E_INVALID for anything else (nothing is launched).  On the device-pointer paths (batched_step,
+ * batched_step_ex, batched_rollout) the kernels cannot raise: a byte b executes as the move table[b & 7] with
+ * 5..7 = NOOP — so no value can index outside a rule table or leave the pitch — and any byte outside 0..4 sets
+ * the sticky SOCCER_MISUSE_ACTION flag (soccer_get_stats / soccer_peek_misuse). */
 typedef struct soccer_step_args {
     const int8_t*  act_a;       /* [n] action of player A, 0..4 */
     const int8_t*  act_b;       /* [n] action of player B, 0..4 */
@@ -209,7 +214,12 @@ int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_hos
  *                           "Please reset the environment before taking a step" (SOCCER_E_INVALID, :376);
  *                           tuples outside the pitch or unreachable are SOCCER_E_INVALID.
  * soccer_reset_scalar: in = u_reset (the ISD draw, :414); out = tuple, poss, t = 0, obs.
- * Both consume one tick and leave the lane's resident state equal to the returned one. */
+ * Both consume one tick and leave the lane's resident state equal to the returned one.
+ * The record: {seq, results, next tuple, flags | t << 8 | check << 16 | seq << 24} written by ONE global_store_dwordx4
+ * to host-mapped memory.  The call accepts it only when word 0 == seq, the top byte of word 3 == seq's low byte AND
+ * the check byte of word 3 equals the byte-sum of words 1 and 2 of the same call — so a record whose four dwords
+ * did not all land (a torn 16-byte write; not observed on gfx950 / PCIe, but not an architectural promise) is
+ * never taken for a complete one: the poll simply continues until they have. */
 typedef struct soccer_scalar_io {
     int8_t row_a, col_a, row_b, col_b;
     uint8_t poss, needs_reset, t;
@@ -294,9 +304,16 @@ int soccer_prob_table(const soccer_handle* h, double prob[12]);
 /* ---- episode statistics ------------------------------------------------------------------ */
 /* hist[0..2] = episodes finished with A's return -1, 0, +1 since create / soccer_reset_stats, counted by
  * batched_rollout and — on handles created with SOCCER_F_STEP_STATS — by batched_step;
- * misuse = nonzero if any lane was stepped while it needed reset (the reference's assert, :376;
- * such lanes are left untouched).  Synchronises the stream. HOST outputs. */
+ * misuse = sticky flags: SOCCER_MISUSE_FROZEN if any lane was stepped while it needed reset (the reference's
+ * assert, :376; such lanes are left untouched), SOCCER_MISUSE_ACTION if any action byte on a device-pointer
+ * path was outside 0..4 (the reference raises IndexError, :393; see "action bytes" above).
+ * Synchronises the stream. HOST outputs. */
+#define SOCCER_MISUSE_FROZEN 1u
+#define SOCCER_MISUSE_ACTION 2u
 int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* misuse);
+/* the misuse flags as they stand, WITHOUT synchronising (the kernels write them to host-mapped memory): what the
+ * launches that have completed so far have raised. */
+uint32_t soccer_peek_misuse(const soccer_handle* h);
 int soccer_reset_stats(soccer_handle* h);
 uint64_t soccer_tick(const soccer_handle* h);
 /* Checkpoint / resume.  The reference keeps (state tuple, timestep, needs_reset, RandomState) per env; here

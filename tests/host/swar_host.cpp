@@ -7,6 +7,7 @@
 
 #include "../../gym_soccer_littman94_amd/csrc/soccer_rules.hpp"
 #include "../../gym_soccer_littman94_amd/csrc/soccer_swar.hpp"
+#include "../../gym_soccer_littman94_amd/csrc/soccer_slip.hpp"
 
 using namespace soccer;
 
@@ -14,25 +15,33 @@ static uint32_t ld4(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); retur
 static void st4(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
 
 // n must be a multiple of 4.  state: six byte streams of n lanes (in / out).  words: one uint32 per lane.
-// slip arrays (nullable together): sa, sb = slipped moves, k = outcome index, cls = slip class per lane.
-// Returns 0, or -1 when the pitch does not qualify for the byte-parallel path.
+// slip_prob > 0: the combination and the quarter are selected from the words by swar::slip_select4 with the tables of
+// soccer_slip.hpp (what soccer_create builds).
+// Returns 0, -1 when the pitch does not qualify for the byte-parallel path, -3 when the slip does not.
 extern "C" int swar_step_host(int width, int height, int max_steps, int autoreset, int general, int full, long n,
                               uint8_t* ra, uint8_t* ca, uint8_t* rb, uint8_t* cb, uint8_t* ps, uint8_t* tt,
-                              const uint8_t* act_a, const uint8_t* act_b, const uint32_t* words,
-                              const uint8_t* sa, const uint8_t* sb, const uint8_t* k, const uint8_t* cls,
+                              const uint8_t* act_a, const uint8_t* act_b, const uint32_t* words, double slip_prob,
                               uint16_t* obs, uint16_t* final_obs, uint8_t* rew, uint8_t* term, uint8_t* trunc,
                               uint8_t* code, uint8_t* finished, uint8_t* frozen, uint8_t* bad) {
     Rules R;
     if (!R.build(width, height).empty()) return -2;
     if (!swar::fits(R.H, R.W, max_steps)) return -1;
     const swar::Consts C = swar::make_consts(R.H, R.W, R.goal_lo, R.goal_hi, max_steps, R.n_isd, R.isd, autoreset != 0);
+    const bool slip = slip_prob != 0.0;
+    SlipTables ST{}; swar::SlipConsts L{};
+    if (slip) {
+        ST = build_slip_tables(slip_prob);
+        if (!ST.swar_ok) return -3;
+        for (int i = 0; i < 9; ++i) L.CB[i] = ST.CB[i];
+        L.c_off = ST.c_off;
+    }
     for (long i = 0; i < n; i += 4) {
         swar::Group S{ld4(ra + i), ld4(ca + i), ld4(rb + i), ld4(cb + i), ld4(ps + i), ld4(tt + i)};
         swar::Out o{};
         const uint32_t a = ld4(act_a + i), b = ld4(act_b + i);
         const uint32_t* w = words + i;
-        const bool slip = sa != nullptr;
-        const uint32_t s_a = slip ? ld4(sa + i) : 0u, s_b = slip ? ld4(sb + i) : 0u, k4 = slip ? ld4(k + i) : 0u, c4 = slip ? ld4(cls + i) : 0u;
+        uint32_t s_a = 0u, s_b = 0u, k4 = 0u, c4 = 0u;
+        if (slip) swar::slip_select4(L, ST.sub, swar::canon4(a), swar::canon4(b), w[0], w[1], w[2], w[3], s_a, s_b, k4, c4);
 #define CALL(G, F, SL) swar::step4<G, F, SL>(C, S, a, b, s_a, s_b, k4, c4, w[0], w[1], w[2], w[3], o)
         if (slip) { if (general) { if (full) CALL(true, true, true); else CALL(true, false, true); }
                     else { if (full) CALL(false, true, true); else CALL(false, false, true); } }

@@ -1,0 +1,285 @@
+"""GPU tests of the byte-parallel kernels (csrc/soccer_swar.hpp: step_kernel_swar, rollout_swar_kernel) through the C ABI:
+every instantiation (lean / full outputs, slip 0 / integer slip selection, fixed policy) against the oracle, every lane,
+every step, on the reference's pitch sizes; the fallbacks they sit next to; and what happens to action bytes outside
+0..4 on every device-pointer path (reference: IndexError at soccer_simultaneous_env.py:393)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from gym_soccer_littman94_amd import SoccerBatch, VectorSoccerEnv
+from oracle.oracle import Oracle
+
+
+def _state_equal(b, o):
+    s = b.get_state()
+    for k, v in (("row_a", o.row_a), ("col_a", o.col_a), ("row_b", o.row_b), ("col_b", o.col_b), ("poss", o.poss & 1),
+                 ("needs_reset", (o.poss >> 1) & 1), ("t", o.t)):
+        np.testing.assert_array_equal(s[k], v, err_msg=k)
+
+
+class _IO:
+    def __init__(self, b, full):
+        n = b.n
+        self.b, self.full = b, full
+        self.aa = b.alloc(n, np.int8); self.ab = b.alloc(n, np.int8)
+        self.obs = b.alloc(n, np.uint16); self.rew = b.alloc(n, np.int8)
+        self.term = b.alloc(n, np.uint8); self.trunc = b.alloc(n, np.uint8)
+        self.code = b.alloc(n, np.uint8) if full else None
+        self.fin = b.alloc(n, np.uint16) if full else None
+
+    def step(self, a, bb):
+        if a is not None: self.aa.upload(a)
+        if bb is not None: self.ab.upload(bb)
+        self.b.step(self.aa if a is not None else None, self.ab if bb is not None else None, obs=self.obs, reward=self.rew,
+                    terminated=self.term, truncated=self.trunc, prob_code=self.code, final_obs=self.fin)
+        out = dict(obs=self.obs.download(), reward=self.rew.download(), terminated=self.term.download(), truncated=self.trunc.download())
+        if self.full:
+            out.update(prob_code=self.code.download(), final_obs=self.fin.download())
+        return out
+
+
+def _check(got, exp, k):
+    for key in got:
+        np.testing.assert_array_equal(got[key], exp[key], err_msg="%s at step %d" % (key, k))
+
+
+@pytest.mark.parametrize("w,h,slip,n", [(5, 4, 0.0, 16384 + 4), (5, 4, 0.2, 16384), (6, 4, 0.5, 8192), (7, 5, 0.3, 8192 + 8),
+                                        (9, 6, 0.0, 8192), (11, 7, 0.0, 8192), (11, 7, 0.2, 8192), (5, 4, 1.0, 4096), (5, 4, 0.05, 4096)])
+@pytest.mark.parametrize("autoreset", [True, False])
+@pytest.mark.parametrize("full", [True, False])
+def test_step_kernel_swar_every_lane_every_step(w, h, slip, n, autoreset, full):
+    """lean (4 outputs) and full (+ prob_code, final_obs, episode histogram) instantiations; without auto-reset the lanes
+    freeze one after the other, so the frozen-lane code runs on a growing share of them"""
+    steps = 140
+    rng = np.random.default_rng(int(slip * 100) + w + 2 * full)
+    b = SoccerBatch(n, w, h, slip, seed=17, autoreset=autoreset, lane_offset=4 * 1000003, step_stats=full)
+    o = Oracle(w, h, slip, n=n, seed=17, autoreset=autoreset, lane_offset=4 * 1000003)
+    io = _IO(b, full)
+    a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+    _check(io.step(a[0], a[1]), o.step(a[0], a[1]), -1)               # before any reset: every lane frozen
+    assert b.stats()[1] == SoccerBatch.MISUSE_FROZEN
+    b.reset_stats(); o.hist[:] = 0
+    b.reset(); o.reset()
+    for k in range(steps):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        _check(io.step(a[0], a[1]), o.step(a[0], a[1]), k)
+    _state_equal(b, o)
+    hist, misuse = b.stats()
+    if full:
+        np.testing.assert_array_equal(hist, o.hist)
+        assert hist.sum() > 0
+    else:
+        assert hist.sum() == 0
+    assert misuse == (0 if autoreset else SoccerBatch.MISUSE_FROZEN) and b.tick == o.tick
+    b.close()
+
+
+@pytest.mark.parametrize("w,h,slip,fixed", [(5, 4, 0.0, "player_b"), (5, 4, 0.2, "player_a"), (7, 5, 0.3, "player_b"), (11, 7, 0.0, "player_a")])
+@pytest.mark.parametrize("full", [True, False])
+def test_step_kernel_swar_fixed_policy(w, h, slip, fixed, full):
+    n, steps = 8192, 110
+    rng = np.random.default_rng(3)
+    o = Oracle(w, h, slip, n=n, seed=23, autoreset=True)
+    policy = rng.integers(0, 5, size=o.nS).astype(np.int8)
+    b = SoccerBatch(n, w, h, slip, seed=23, autoreset=True, step_stats=False)
+    b.set_policy(fixed, policy)
+    io = _IO(b, full)
+    obs0 = b.alloc(n, np.uint16); b.reset(obs=obs0)
+    cur = o.reset()
+    np.testing.assert_array_equal(obs0.download(), cur)
+    for k in range(steps):
+        act = rng.integers(0, 5, size=n, dtype=np.int8)
+        a, bb = (policy[cur], act) if fixed == "player_a" else (act, policy[cur])
+        c = o.step(a, bb)
+        _check(io.step(None if fixed == "player_a" else act, None if fixed == "player_b" else act), c, k)
+        cur = c["obs"]
+    _state_equal(b, o)
+    b.close()
+
+
+def _rollout_vs_oracle(b, o, acts, T, n, sample=False, mix=None):
+    A = B = None
+    if not sample:
+        A = b.alloc((T, n), np.int8).upload(acts[:, 0]); B = b.alloc((T, n), np.int8).upload(acts[:, 1])
+    obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8); term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
+    rs = b.alloc(n, np.int32).fill(0); ec = b.alloc(n, np.int32).fill(0)
+    lut = o.tables()[0]
+    f = ((((o.row_a.astype(np.int64) * o.W + o.col_a) * o.H + o.row_b) * o.W + o.col_b) << 1) | (o.poss & 1)
+    cur = lut[f]
+    da = db = None
+    if mix is not None:
+        da = b.alloc(mix[0].shape, np.uint16).upload(mix[0]); db = b.alloc(mix[1].shape, np.uint16).upload(mix[1])
+    b.rollout(T, A, B, act_stride=n, sample_actions=sample, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
+              return_sum=rs, episode_count=ec, mix_a=da, mix_b=db)
+    O, R, TE, TR = obs.download(), rew.download(), term.download(), trunc.download()
+    ret = np.zeros(n, np.int64); eps = np.zeros(n, np.int64)
+    for k in range(T):
+        if sample:
+            a, bb = o.sample_actions_mixed(cur, *(mix if mix is not None else (None, None)))
+        else:
+            a, bb = acts[k, 0], acts[k, 1]
+        c = o.step(a, bb)
+        np.testing.assert_array_equal(O[k], c["obs"], err_msg="obs %d" % k); np.testing.assert_array_equal(R[k], c["reward"], err_msg="reward %d" % k)
+        np.testing.assert_array_equal(TE[k], c["terminated"]); np.testing.assert_array_equal(TR[k], c["truncated"])
+        frozen = ((o.poss >> 1) & 1).astype(bool) if not o.autoreset else np.zeros(n, bool)
+        ret += c["reward"]; eps += ((c["terminated"] | c["truncated"]) != 0)
+        cur = c["obs"]
+    _state_equal(b, o)
+    np.testing.assert_array_equal(rs.download(), ret)
+    np.testing.assert_array_equal(b.stats()[0], o.hist)
+    return ec.download(), eps
+
+
+@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (7, 5, 0.0), (9, 6, 0.0), (11, 7, 0.0), (5, 4, 0.2), (11, 7, 0.3), (6, 4, 1.0)])
+def test_rollout_swar_streams_every_lane_every_step(w, h, slip):
+    n, T = 8192, 120
+    rng = np.random.default_rng(w + int(10 * slip))
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    for autoreset in (True, False):
+        b = SoccerBatch(n, w, h, slip, seed=4, autoreset=autoreset); o = Oracle(w, h, slip, n=n, seed=4, autoreset=autoreset)
+        b.reset(); o.reset()
+        ec, eps = _rollout_vs_oracle(b, o, acts, T, n)
+        if autoreset:
+            np.testing.assert_array_equal(ec, eps)
+            assert eps.sum() > n // 2
+        else:
+            assert b.stats()[1] == SoccerBatch.MISUSE_FROZEN          # lanes that finished were stepped again: left untouched
+        # a second rollout continues from the state the first one left (frozen lanes included), goal tuples injected
+        lut, kind, gv, isd, isdp = o.tables()
+        goal = np.flatnonzero(kind == 2)[:64]
+        st = b.get_state()
+        for name, div in (("poss", 1), ("col_b", 2), ("row_b", 2 * o.W), ("col_a", 2 * o.W * o.H), ("row_a", 2 * o.W * o.H * o.W)):
+            mod = {"poss": 2, "col_b": o.W, "row_b": o.H, "col_a": o.W, "row_a": 1 << 30}[name]
+            st[name][:64] = (goal // div) % mod
+        st["needs_reset"][:64] = 0; st["t"][:64] = 5
+        b.set_state(st["row_a"], st["col_a"], st["row_b"], st["col_b"], st["poss"], t=st["t"], needs_reset=st["needs_reset"])
+        o.set_state(st["row_a"], st["col_a"], st["row_b"], st["col_b"], st["poss"], t=st["t"], needs_reset=st["needs_reset"])
+        b.reset_stats(); o.hist[:] = 0
+        _rollout_vs_oracle(b, o, acts[:40], 40, n)
+        b.close()
+
+
+@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (5, 4, 0.2), (11, 7, 0.0)])
+def test_rollout_swar_sampled_and_mixed_policies(w, h, slip):
+    """in-kernel sampling: uniform, and from [nS, 4] mixed-policy thresholds — staged in LDS on 5x4, gathered from global
+    memory on 11x7 (nS = 11 705 rows do not fit next to each other in 64 KB)"""
+    n, T = 8192, 100
+    rng = np.random.default_rng(31)
+    o = Oracle(w, h, slip, n=n, seed=8, autoreset=True)
+    mix = (SoccerBatch.mixed_policy_thresholds(rng.dirichlet(np.ones(5) * 0.6, size=o.nS)),
+           SoccerBatch.mixed_policy_thresholds(rng.dirichlet(np.ones(5) * 0.6, size=o.nS)))
+    for m in (None, mix):
+        b = SoccerBatch(n, w, h, slip, seed=8, autoreset=True); o = Oracle(w, h, slip, n=n, seed=8, autoreset=True)
+        b.reset(); o.reset()
+        ec, eps = _rollout_vs_oracle(b, o, None, T, n, sample=True, mix=m)
+        np.testing.assert_array_equal(ec, eps)
+        b.close()
+
+
+def test_fallback_rollout_still_matches(monkeypatch):
+    """SOCCER_ROLLOUT=1 keeps the per-lane rollout kernel (what slips like 0.1 and pitches beyond the byte arithmetic take)"""
+    monkeypatch.setenv("SOCCER_ROLLOUT", "1")
+    n, T = 4096, 60
+    rng = np.random.default_rng(2)
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    for slip in (0.0, 0.2, 0.1):
+        b = SoccerBatch(n, 5, 4, slip, seed=4, autoreset=True); o = Oracle(5, 4, slip, n=n, seed=4, autoreset=True)
+        b.reset(); o.reset()
+        _rollout_vs_oracle(b, o, acts, T, n)
+        b.close()
+
+
+# ---- action bytes outside 0..4 ---------------------------------------------------------------------------------------------
+BAD = np.array([5, 6, 7, 8, 127, -1, -128, -123], np.int8)
+
+
+def _reachable(b, o):
+    lut, kind, *_ = o.tables()
+    s = b.get_state()
+    ra, ca, rb, cb, p = (s[k].astype(np.int64) for k in ("row_a", "col_a", "row_b", "col_b", "poss"))
+    assert (ra >= 0).all() and (ra < o.H).all() and (rb >= 0).all() and (rb < o.H).all()
+    assert (ca >= 0).all() and (ca < o.W).all() and (cb >= 0).all() and (cb < o.W).all()
+    assert (kind[(((ra * o.W + ca) * o.H + rb) * o.W + cb) * 2 + p] != 0).all()
+
+
+@pytest.mark.parametrize("path", ["swar_lean", "swar_full", "generic", "hot_slip_0p1", "rollout_swar", "rollout_fallback"])
+def test_bad_action_bytes_on_device_paths_stay_inside_the_tables_and_are_flagged(path, monkeypatch):
+    n, T = 8192, 30
+    slip = 0.1 if path == "hot_slip_0p1" else 0.0
+    if path == "rollout_fallback":
+        monkeypatch.setenv("SOCCER_ROLLOUT", "1")
+    rng = np.random.default_rng(6)
+    b = SoccerBatch(n, 5, 4, slip, seed=1, autoreset=True, step_stats=False)
+    o = Oracle(5, 4, slip, n=n, seed=1, autoreset=True)
+    b.reset()
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    poison = rng.random((T, 2, n)) < 0.02
+    acts[poison] = BAD[rng.integers(0, len(BAD), size=int(poison.sum()))]
+    A = b.alloc((T, n), np.int8).upload(acts[:, 0]); B = b.alloc((T, n), np.int8).upload(acts[:, 1])
+    obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8); term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
+    code = b.alloc(n, np.uint8); last = b.alloc(n, np.int8).fill(0)
+    assert b.stats()[1] == 0
+    if path.startswith("rollout"):
+        b.rollout(T, A, B, act_stride=n, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n)
+    else:
+        for k in range(T):
+            kw = {}
+            if path == "swar_full": kw = dict(prob_code=code)
+            if path == "generic": kw = dict(prob_code=code, last_return=last)
+            b.step(A.row(k), B.row(k), obs=obs.row(k), reward=rew.row(k), terminated=term.row(k), truncated=trunc.row(k), **kw)
+    assert b.stats()[1] == SoccerBatch.MISUSE_ACTION and b.peek_misuse() == SoccerBatch.MISUSE_ACTION
+    _reachable(b, o)
+    O = obs.download()
+    assert (O < b.nS).all() and (np.abs(rew.download()) <= 1).all()
+    # the semantics: a byte executes as (byte & 7) with 5..7 -> NOOP — i.e. exactly what the oracle does on the mapped action
+    canon = acts.view(np.uint8) & 7
+    canon[canon > 4] = 0
+    b2 = SoccerBatch(n, 5, 4, slip, seed=1, autoreset=True, step_stats=False); b2.reset(); o.reset()
+    for k in range(T):
+        c = o.step(canon[k, 0].astype(np.int8), canon[k, 1].astype(np.int8))
+        np.testing.assert_array_equal(O[k], c["obs"], err_msg="step %d" % k)
+    _state_equal(b, o)
+    b.reset_stats()
+    assert b.stats()[1] == 0
+    b.close(); b2.close()
+
+
+def test_bad_actions_on_host_paths_are_refused_before_any_launch():
+    n = 1000
+    b = SoccerBatch(n, 5, 4, 0.0, seed=1, autoreset=True)
+    b.reset()
+    tick = b.tick
+    good = np.zeros(n, np.int8)
+    for v in (5, 127, -1, -128):
+        bad = good.copy(); bad[n - 3] = v
+        with pytest.raises(AssertionError, match="actions must be in 0..4"):
+            b.step_host(good, bad)
+        with pytest.raises(AssertionError, match="player_a in lane %d" % (n - 3)):
+            b.step_host(bad, good)
+    assert b.tick == tick and b.stats()[1] == 0          # nothing was launched
+    b.step_host(good, good)
+    b.close()
+
+
+def test_vector_env_strict_mode_reports_bad_device_actions():
+    import torch
+    n = 4096
+    v = VectorSoccerEnv(n, seed=0, io="device")
+    v.reset()
+    ok = torch.zeros(n, dtype=torch.int8, device="cuda")
+    bad = ok.clone(); bad[17] = -1
+    v.step({"player_a": ok, "player_b": ok})
+    v.step({"player_a": bad, "player_b": ok})
+    torch.cuda.synchronize()
+    with pytest.raises(AssertionError, match="actions must be in 0..4"):
+        v.step({"player_a": ok, "player_b": ok})
+    v.step({"player_a": ok, "player_b": ok})                 # the flag was cleared with the report
+    v.close()
+    vn = VectorSoccerEnv(64, seed=0)
+    vn.reset()
+    with pytest.raises(AssertionError, match="0..4"):
+        vn.step({"player_a": np.full(64, 5), "player_b": np.zeros(64, np.int64)})
+    vn.close()

@@ -23,7 +23,7 @@ def host(tmp_path_factory):
                            os.path.join(ROOT, "tests", "host", "swar_host.cpp")])
     L = C.CDLL(so)
     L.swar_step_host.restype = C.c_int
-    L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 22
+    L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 9
     return L
 
 
@@ -39,7 +39,7 @@ def _tuples(o, kinds):
     return np.stack([ra, ca, rb, cb, p], 1).astype(np.int64)
 
 
-def _run_swar(L, w, h, max_steps, autoreset, general, full, st, t, need, aa, ab, words, slip=None):
+def _run_swar(L, w, h, max_steps, autoreset, general, full, st, t, need, aa, ab, words, slip=0.0):
     n = len(t)
     ra, ca, rb, cb = (np.ascontiguousarray(st[:, k], np.uint8) for k in range(4))
     ps = np.ascontiguousarray(st[:, 4] | (need << 1), np.uint8)
@@ -47,11 +47,10 @@ def _run_swar(L, w, h, max_steps, autoreset, general, full, st, t, need, aa, ab,
     out = dict(obs=np.zeros(n, np.uint16), final_obs=np.zeros(n, np.uint16), reward=np.zeros(n, np.uint8),
                terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), prob_code=np.zeros(n, np.uint8),
                finished=np.zeros(n, np.uint8), frozen=np.zeros(n, np.uint8), bad=np.zeros(n // 4, np.uint8))
-    sl = [None] * 4 if slip is None else [np.ascontiguousarray(x, np.uint8) for x in slip]
     rc = L.swar_step_host(w, h, max_steps, int(autoreset), int(general), int(full), n,
                           _p(ra), _p(ca), _p(rb), _p(cb), _p(ps), _p(tt),
                           _p(np.ascontiguousarray(aa, np.uint8)), _p(np.ascontiguousarray(ab, np.uint8)),
-                          _p(np.ascontiguousarray(words, np.uint32)), _p(sl[0]), _p(sl[1]), _p(sl[2]), _p(sl[3]),
+                          _p(np.ascontiguousarray(words, np.uint32)), float(slip),
                           _p(out["obs"]), _p(out["final_obs"]), _p(out["reward"]), _p(out["terminated"]),
                           _p(out["truncated"]), _p(out["prob_code"]), _p(out["finished"]), _p(out["frozen"]), _p(out["bad"]))
     assert rc == 0
@@ -81,9 +80,9 @@ def _grid(tup, t_values, need_values, rng):
     return tup[ti], t, need.astype(np.int64), aa, ab, words
 
 
-def _oracle_step(w, h, max_steps, autoreset, st, t, need, aa, ab, words):
+def _oracle_step(w, h, max_steps, autoreset, st, t, need, aa, ab, words, slip=0.0):
     n = len(t)
-    o = Oracle(w, h, 0.0, n=n, autoreset=autoreset, max_steps=max_steps)
+    o = Oracle(w, h, slip, n=n, autoreset=autoreset, max_steps=max_steps)
     o.set_state(st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], t=t, needs_reset=need)
     c = o.step(aa, ab, u_step=(words >> 2).astype(np.float64) * 2.0 ** -30, u_reset=(words & 3).astype(np.float64) * 0.25)
     c["state"] = (o.row_a.view(np.uint8), o.col_a.view(np.uint8), o.row_b.view(np.uint8), o.col_b.view(np.uint8), o.poss, o.t)
@@ -173,3 +172,69 @@ def test_actions_outside_0_4_are_reported_and_never_leave_the_pitch(host):
     clean = np.repeat(~flagged, 4)
     for k in ("obs", "reward", "terminated", "truncated"):
         np.testing.assert_array_equal(got[k][clean], exp[k][clean])
+
+
+# ---- slip_prob > 0: per-lane combination / quarter selection (integer thresholds) + the byte-parallel step ----------------
+def _slip_words(slip, n, rng):
+    """draws that cover every combination and every quarter of each: uniform words, plus words sitting exactly on, one
+    below and one above every scaled threshold of the handle (the integer decision must flip exactly there)"""
+    s = slip
+    c = [(1 - s) * (1 - s), (1 - s) * s * 0.5, (1 - s) * s * 0.5, s * (1 - s) * 0.5, s * (1 - s) * 0.5] + [s * s * 0.25] * 4
+    edges = []
+    acc = 0.0
+    for wgt in c:
+        if wgt == 0.0:
+            continue
+        for q in (0.25, 0.5, 0.75, 1.0):
+            edges.append(acc + wgt * q)
+        acc += wgt
+    m_edge = np.array([int(np.ceil(e * 2 ** 30)) for e in edges if e < 1.0], dtype=np.int64)
+    special = np.concatenate([m_edge - 1, m_edge, m_edge + 1, [0, 1, 2 ** 30 - 1]])
+    special = special[(special >= 0) & (special < 2 ** 30)]
+    m = rng.integers(0, 1 << 30, size=n, dtype=np.int64)
+    pick = rng.random(n) < 0.25
+    m[pick] = special[rng.integers(0, len(special), size=int(pick.sum()))]
+    return ((m << 2) | rng.integers(0, 4, size=n)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.2), (5, 4, 0.5), (5, 4, 1.0), (5, 4, 0.3), (5, 4, 0.05), (7, 5, 0.3), (11, 7, 0.2)])
+def test_slip_step_every_tuple_and_action_with_draws_on_every_threshold(host, w, h, slip):
+    rng = np.random.default_rng(int(slip * 100) + w)
+    o = Oracle(w, h, slip, n=1)
+    tup = _tuples(o, [1, 2])
+    reps = 6 if w == 5 else 2
+    idx = np.arange(len(tup) * 25 * reps)
+    ti = idx // (25 * reps); r = idx % (25 * reps)
+    aa = (r // reps) // 5; ab = (r // reps) % 5
+    n = len(idx) - len(idx) % 4
+    ti, aa, ab = ti[:n], aa[:n], ab[:n]
+    words = _slip_words(slip, n, rng)
+    t = np.asarray([0, 40, 98, 99, 100])[rng.integers(0, 5, size=n)]
+    need = (rng.random(n) < 0.2).astype(np.int64)
+    t = np.where(need == 1, t, np.minimum(t, 99))
+    st = tup[ti]
+    for autoreset in (True, False):
+        got = _run_swar(host, w, h, 100, autoreset, True, True, st, t, need, aa, ab, words, slip=slip)
+        exp = _oracle_step(w, h, 100, autoreset, st, t, need, aa, ab, words, slip=slip)
+        _compare(got, exp, need, True)
+    # the lean, steady-state instantiation on live tuples
+    live = _tuples(o, [1])
+    st = live[rng.integers(0, len(live), size=n)]; need0 = np.zeros(n, np.int64); t0 = np.minimum(t, 99)
+    got = _run_swar(host, w, h, 100, True, False, False, st, t0, need0, aa, ab, words, slip=slip)
+    exp = _oracle_step(w, h, 100, True, st, t0, need0, aa, ab, words, slip=slip)
+    _compare(got, exp, need0, False)
+
+
+def test_slips_with_a_near_integer_threshold_do_not_qualify(host):
+    """0.1 / 0.9 have a scaled threshold within 2^-10 of an integer (slip_int == 2): those handles stay on the per-lane
+    kernels, which send such a draw down the float64 walk"""
+    n = 4
+    z = np.zeros(n, np.uint8)
+    for slip, rc_expected in ((0.1, -3), (0.9, -3), (0.2, 0)):
+        out16 = np.zeros(n, np.uint16)
+        rc = host.swar_step_host(5, 4, 100, 1, 1, 0, n, _p(np.full(n, 1, np.uint8)), _p(np.full(n, 2, np.uint8)),
+                                 _p(np.full(n, 2, np.uint8)), _p(np.full(n, 4, np.uint8)), _p(z.copy()), _p(z.copy()),
+                                 _p(z.copy()), _p(z.copy()), _p(np.zeros(n, np.uint32)), float(slip),
+                                 _p(out16), _p(out16.copy()), _p(z.copy()), _p(z.copy()), _p(z.copy()), _p(z.copy()),
+                                 _p(z.copy()), _p(z.copy()), _p(np.zeros(1, np.uint8)))
+        assert rc == rc_expected, (slip, rc)
