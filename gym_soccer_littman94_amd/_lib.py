@@ -110,6 +110,8 @@ PROTOTYPES = {
     "soccer_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "soccer_timer_start": (C.c_int, [C.c_void_p]),
     "soccer_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "soccer_timer_mark": (C.c_int, [C.c_void_p]),
+    "soccer_timer_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "soccer_graph_begin": (C.c_int, [C.c_void_p]),
     "soccer_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "soccer_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

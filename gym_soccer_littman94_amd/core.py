@@ -415,6 +415,15 @@ class SoccerBatch:
         self._check(self.lib.soccer_timer_stop(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def timer_mark(self):
+        """Record the closing event (allowed inside a graph capture, like timer_start)."""
+        self._check(self.lib.soccer_timer_mark(self.h))
+
+    def timer_read(self):
+        ms = C.c_float()
+        self._check(self.lib.soccer_timer_read(self.h, C.byref(ms)))
+        return float(ms.value)
+
     # -- hipGraph capture ----------------------------------------------------------------------
     def graph_begin(self):
         self._check(self.lib.soccer_graph_begin(self.h))

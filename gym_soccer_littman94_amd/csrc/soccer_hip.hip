@@ -67,6 +67,7 @@ struct soccer_handle {
     // byte-parallel step (soccer_swar.hpp)
     swar::Consts swar_c{}; bool swar_ok = false;
     swar::SlipConsts slip_c{}; bool slip_swar_ok = false;   // integer slip selection usable by the byte-parallel kernels
+    bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
@@ -276,6 +277,7 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     }
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device) == hipSuccess && khz > 0) h->wall_clock_khz = khz; }
     h->grid_cap = prop.multiProcessorCount * 8;
     h->n_cu = prop.multiProcessorCount;
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -1161,16 +1163,55 @@ extern "C" int soccer_memset(soccer_handle* h, void* dst, int value, size_t byte
     return SOCCER_OK;
 }
 
+// Inside a graph capture an event record becomes a node that carries no timestamp (hipEventElapsedTime refuses such
+// events), so a captured timer_start / timer_mark is a one-thread kernel that stores the device's constant-rate wall clock
+// into the handle's host-mapped block instead; soccer_timer_read converts the difference.
+__global__ void stamp_kernel(unsigned long long* slot) {
+    if (threadIdx.x == 0) *slot = wall_clock64();
+}
+
 extern "C" int soccer_timer_start(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    h->timer_stamped = h->capturing;
+    if (h->capturing) {
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<unsigned long long*>(h->d_misuse + 16));
+        HIP_TRY(h, hipGetLastError());
+        return SOCCER_OK;
+    }
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     return SOCCER_OK;
 }
-extern "C" int soccer_timer_stop(soccer_handle* h, float* elapsed_ms) {
-    if (!h || !elapsed_ms) return fail(h, SOCCER_E_INVALID, "handle/elapsed_ms is NULL");
+extern "C" int soccer_timer_mark(soccer_handle* h) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->capturing) {
+        if (!h->timer_stamped) return fail(h, SOCCER_E_STATE, "soccer_timer_mark in a capture needs soccer_timer_start in the same capture");
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<unsigned long long*>(h->d_misuse + 18));
+        HIP_TRY(h, hipGetLastError());
+        return SOCCER_OK;
+    }
+    h->timer_stamped = false;
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    return SOCCER_OK;
+}
+extern "C" int soccer_timer_read(soccer_handle* h, float* elapsed_ms) {
+    if (!h || !elapsed_ms) return fail(h, SOCCER_E_INVALID, "handle/elapsed_ms is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_timer_read during graph capture");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->timer_stamped) {                 // the stamps of the last replay of a graph that captured start / mark
+        for (uint32_t spins = 0;; ++spins) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+            if (spins > 2000u) { (void)hipGetLastError(); HIP_TRY(h, hipStreamSynchronize(h->stream)); break; }
+            __builtin_ia32_pause();
+        }
+        (void)hipGetLastError();
+        const volatile unsigned long long* st = reinterpret_cast<const volatile unsigned long long*>(h->misuse_host + 16);
+        *elapsed_ms = (float)((double)(st[1] - st[0]) / (double)h->wall_clock_khz);
+        return SOCCER_OK;
+    }
     // poll instead of blocking: a blocked waiter is woken tens of microseconds after the event completes, which is
     // as long as the whole timed region of a short run
     for (uint32_t spins = 0;; ++spins) {
@@ -1183,6 +1224,10 @@ extern "C" int soccer_timer_stop(soccer_handle* h, float* elapsed_ms) {
     (void)hipGetLastError();
     HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     return SOCCER_OK;
+}
+extern "C" int soccer_timer_stop(soccer_handle* h, float* elapsed_ms) {
+    if (int rc = soccer_timer_mark(h)) return rc;
+    return soccer_timer_read(h, elapsed_ms);
 }
 
 // ------------------------------------------------------------------------------------------------

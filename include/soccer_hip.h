@@ -328,9 +328,13 @@ int soccer_free(soccer_handle* h, void* dptr);
 int soccer_memcpy_h2d(soccer_handle* h, void* dst, const void* src, size_t bytes); /* sync */
 int soccer_memcpy_d2h(soccer_handle* h, void* dst, const void* src, size_t bytes); /* sync */
 int soccer_memset(soccer_handle* h, void* dst, int value, size_t bytes);           /* async */
-/* HIP events on the handle's stream */
+/* HIP events on the handle's stream.  soccer_timer_start / soccer_timer_mark may also be called during a graph
+ * capture: the two event records then become nodes of the graph, and after a replay soccer_timer_read returns the
+ * device time between them — first captured kernel's start to last one's end, without the replay's start-up latency. */
 int soccer_timer_start(soccer_handle* h);
-int soccer_timer_stop(soccer_handle* h, float* elapsed_ms);   /* synchronises */
+int soccer_timer_mark(soccer_handle* h);                       /* records the closing event */
+int soccer_timer_read(soccer_handle* h, float* elapsed_ms);    /* waits for the closing event */
+int soccer_timer_stop(soccer_handle* h, float* elapsed_ms);    /* = mark + read */
 
 /* ---- hipGraph capture of a sequence of batched_* calls ------------------------------------ */
 /* Calls between begin and end are recorded instead of executed.  The number of recorded
