@@ -166,6 +166,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to bench)")
     gloo = args.dist_backend == "gloo"
+    if not gloo and local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible (one rank per GPU; --dist-backend gloo "
+                         "rehearses more ranks than GPUs)" % (rank, local_rank, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count() if gloo else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -299,7 +302,7 @@ def main():
         bytes_per = 7 + 12.0 / T                         # 2 B actions in, 5 B out, state amortised over T
         rollout = {"steps_fused": T, "env_steps_per_s": world * N * T / (r_ms * 1e-3),
                    "bytes_per_env_step": bytes_per,
-                   "achieved_GBps": bytes_per * N * T / (r_ms * 1e-3) / 1e9}
+                   "achieved_GBps": bytes_per * world * N * T / (r_ms * 1e-3) / 1e9}
 
     # ---- optional: BASELINE config 5 shape — both players sample from [nS, 5] mixed policies in-kernel --
     selfplay = None
@@ -388,7 +391,7 @@ def main():
                          "bound_note": "bytes counted at the L2<->fabric boundary (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits "
                                        "are included, and the ~%d MB working set of a run fits the 256 MB Infinity Cache when K is small"
                                        % ((12 * N + 7 * N * K) >> 20),
-                         "kernel": "soccer::step_kernel_swar<false>" if not args.slip else "soccer::step_kernel_hot<true, ...>",
+                         "kernel": "soccer::step_kernel_swar<false, %s, false>" % ("true" if args.slip else "false"),
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
             "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
                          "gathered_last_returns": int(gathered.numel()),
