@@ -105,6 +105,11 @@ struct Consts {
     uint32_t isd_ca4, isd_cb4;        // the entries' columns (2 and W - 3) in every byte
     uint32_t isd_shift, isd_mask;     // entry index = (two random bits >> shift), 4 or 2 entries
     uint32_t autoreset;
+    // small pitches: the clamps of a cell move as 8-entry byte tables (one v_perm_b32 instead of ~8 instructions)
+    uint32_t row_lut;                 // != 0: H <= 6, row_lo / row_hi[u] = clamp(u - 1, 0, H - 1) for u = row + 1 + drow in 0..H+1
+    uint32_t row_lo, row_hi;
+    uint32_t col_lut;                 // != 0: W <= 8, col_lo / col_hi[c] = clamp(c, 1, W - 2): a step into a goal column undone
+    uint32_t col_lo, col_hi;
 };
 
 // A pitch qualifies when every byte quantity stays below 128 (bit 7 is the guard bit):
@@ -137,6 +142,19 @@ inline Consts make_consts(int H, int W, int goal_lo, int goal_hi, int max_steps,
     C.isd_shift = n_isd == 4 ? 0u : 1u;
     C.isd_mask = n_isd == 4 ? 0x03030303u : K01;
     C.autoreset = autoreset ? 1u : 0u;
+    auto table = [](int n, int lo, int hi, int bias, uint32_t& tlo, uint32_t& thi) {
+        uint64_t t = 0;
+        for (int u = 0; u < 8; ++u) {
+            int v = (u < n ? u : n - 1) - bias;
+            v = v < lo ? lo : (v > hi ? hi : v);
+            t |= (uint64_t)(uint8_t)v << (8 * u);
+        }
+        tlo = (uint32_t)t; thi = (uint32_t)(t >> 32);
+    };
+    C.row_lut = H + 2 <= 8 ? 1u : 0u;
+    if (C.row_lut) table(H + 2, 0, H - 1, 1, C.row_lo, C.row_hi);
+    C.col_lut = W <= 8 ? 1u : 0u;
+    if (C.col_lut) table(W, 1, W - 2, 0, C.col_lo, C.col_hi);
     return C;
 }
 
@@ -174,13 +192,22 @@ constexpr uint32_t T_SLIP2_LO = 0x01030400u, T_SLIP2_HI = 0x00000002u;
 // `score` = flag word "holds the ball and is in a goal row" (an EAST / WEST move never changes the row).
 SOCCER_HD void move4(const Consts& C, uint32_t r, uint32_t c, uint32_t mv, uint32_t score, uint32_t& nr, uint32_t& nc) {
     const uint32_t u = r + lut8(T_DR1_HI, T_DR1_LO, mv);                   // row + 1 + drow, in 0 .. H + 1
-    const uint32_t at_top = one_of(is_zero(u));                            // stepped north off row 0
-    const uint32_t at_bot = one_of(is_zero(u ^ C.Hp1x4));                  // stepped south off row H - 1
-    nr = u + at_top + 0xFEFEFEFFu - at_bot;                                // clamp (:365); (u + at_top) >= 1 in every byte
+    if (C.row_lut) {                                                       // wave-uniform
+        nr = perm(C.row_hi, C.row_lo, u);                                  // clamp (:365) by table
+    } else {
+        const uint32_t at_top = one_of(is_zero(u));                        // stepped north off row 0
+        const uint32_t at_bot = one_of(is_zero(u ^ C.Hp1x4));              // stepped south off row H - 1
+        nr = u + at_top + 0xFEFEFEFFu - at_bot;                            // (u + at_top) >= 1 in every byte
+    }
     const uint32_t ct = c + lut8(T_E_HI, T_E_LO, mv) - lut8(T_W_HI, T_W_LO, mv);   // :366
-    const uint32_t edge = is_zero(ct) | is_zero(ct ^ C.Wm1x4);            // the target is a goal column (:369)
-    const uint32_t revert = bfi(score, 0u, edge);                          // ... and this is not a score (:370-372)
-    nc = bfi(mask_of(revert), c, ct);
+    if (C.col_lut) {
+        // a step into a goal column that is not a score is undone (:369-372): from column 1 / W - 2 that is a clamp
+        nc = bfi(mask_of(score), ct, perm(C.col_hi, C.col_lo, ct));
+    } else {
+        const uint32_t edge = is_zero(ct) | is_zero(ct ^ C.Wm1x4);        // the target is a goal column (:369)
+        const uint32_t revert = bfi(score, 0u, edge);                      // ... and this is not a score (:370-372)
+        nc = bfi(mask_of(revert), c, ct);
+    }
 }
 
 // ---- slip: which of the nine combinations a lane's draw selects, and where in it the draw falls -------------------
@@ -299,8 +326,9 @@ SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw
     // ---- the outcome draw ---------------------------------------------------------------------------------------------
     // kb1 / kb0: flag words of bit 1 / bit 0 of the outcome index k (coin lists use k = bit 1 of the two-bit draw)
     uint32_t kb1, kb0c, kb0f;                                              // kb0 for coin lists / for four-way lists
+    // the top byte (outcome draw) and the low byte (reset draw) of the four random words, packed pairwise once
+    const uint32_t x01 = perm(w1, w0, 0x04000703u), x23 = perm(w3, w2, 0x04000703u);
     if (!SLIP) {
-        const uint32_t x01 = perm(w1, w0, 0x0c0c0703u), x23 = perm(w3, w2, 0x0c0c0703u);
         const uint32_t T4 = perm(x23, x01, 0x05040100u);                   // byte j = top byte of lane j's word
         kb1 = T4; kb0c = T4; kb0f = T4 << 1;                               // floor(2u) / floor(4u): bits 31 and 30
     } else {
@@ -338,8 +366,7 @@ SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw
     uint32_t obs_zero7 = goal7;
     if (!GENERAL || C.autoreset) {                                         // wave-uniform
         const uint32_t rm = mask_of(fin7);
-        const uint32_t y01 = perm(w1, w0, 0x0c0c0400u), y23 = perm(w3, w2, 0x0c0c0400u);
-        const uint32_t idx = (perm(y23, y01, 0x05040100u) >> C.isd_shift) & C.isd_mask;
+        const uint32_t idx = (perm(x23, x01, 0x07060302u) >> C.isd_shift) & C.isd_mask;   // byte j = low byte of lane j's word
         fra = bfi(rm, perm(0u, C.isd_ra, idx), fra); fca = bfi(rm, C.isd_ca4, fca);
         frb = bfi(rm, perm(0u, C.isd_rb, idx), frb); fcb = bfi(rm, C.isd_cb4, fcb);
         p01 = bfi(rm, perm(0u, C.isd_p, idx), p01);
