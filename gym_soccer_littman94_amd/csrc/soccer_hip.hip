@@ -67,6 +67,7 @@ struct soccer_handle {
     // byte-parallel step (soccer_swar.hpp)
     swar::Consts swar_c{}; bool swar_ok = false;
     swar::SlipConsts slip_c{}; bool slip_swar_ok = false;   // integer slip selection usable by the byte-parallel kernels
+    KernelParams* d_params = nullptr;       // slip_int == 2: device copy of P for the rare float64 walk inside those kernels
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
@@ -111,7 +112,7 @@ static void free_handle(soccer_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_params};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -280,6 +281,10 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device) == hipSuccess && khz > 0) h->wall_clock_khz = khz; }
     h->grid_cap = prop.multiProcessorCount * 8;
     h->n_cu = prop.multiProcessorCount;
+    if (h->slip_swar_ok && P.slip_int == 2u) {
+        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_params), sizeof(KernelParams)));
+        CREATE_TRY(hipMemcpy(h->d_params, &h->P, sizeof(KernelParams), hipMemcpyHostToDevice));
+    }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     *out = h;
@@ -378,14 +383,14 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
         const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
         const bool full = io.prob_code || io.final_obs || P.step_stats;
         SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr,
-                     h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.policy_a, P.policy_b,
+                     h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_params, P.policy_a, P.policy_b,
                      io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs};
 #define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
 #define SWAR_GO(FV, SV, PV) hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV>), gh, b, 0, h->stream, SWAR_ARGS)
-        if (policy_only) { if (h->slip) { if (full) SWAR_GO(true, true, true); else SWAR_GO(false, true, true); }
-                           else { if (full) SWAR_GO(true, false, true); else SWAR_GO(false, false, true); } }
-        else { if (h->slip) { if (full) SWAR_GO(true, true, false); else SWAR_GO(false, true, false); }
-               else { if (full) SWAR_GO(true, false, false); else SWAR_GO(false, false, false); } }
+#define SWAR_SLIP(FV, PV) do { if (!h->slip) SWAR_GO(FV, 0, PV); else if (P.slip_int == 2u) SWAR_GO(FV, 2, PV); else SWAR_GO(FV, 1, PV); } while (0)
+        if (policy_only) { if (full) SWAR_SLIP(true, true); else SWAR_SLIP(false, true); }
+        else { if (full) SWAR_SLIP(true, false); else SWAR_SLIP(false, false); }
+#undef SWAR_SLIP
 #undef SWAR_GO
 #undef SWAR_ARGS
     } else if (policy_only && vec && shared && lean0) {                     // the per-lane hot kernel with the policy lookup
@@ -515,7 +520,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
             RolloutSwar RS{P.state, P.state_stride, P.first, P.n, P.lane_offset, P.tick_in, P.tick_out, P.hist, P.misuse,
                            P.policy_a, P.policy_b, P.key0, P.key1,
-                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), R0.nS, 0};
+                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_params, R0.nS, 0};
             size_t smem = 36 * sizeof(uint32_t);
             if (dyn) {
                 const size_t need = smem + 2 * (size_t)R0.nS * sizeof(uint2) + 2 * (((size_t)R0.nS + 15) & ~size_t(15));
@@ -527,8 +532,10 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             const dim3 g((unsigned)blocks), bl(kBlock);
 #define LAUNCH_S(DV, SV) do { if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
                               hipLaunchKernelGGL((rollout_swar_kernel<DV, SV>), g, bl, smem, h->stream, RS, io); } while (0)
-            if (h->slip) { if (dyn) LAUNCH_S(true, true); else LAUNCH_S(false, true); }
-            else { if (dyn) LAUNCH_S(true, false); else LAUNCH_S(false, false); }
+            const int sm = !h->slip ? 0 : (P.slip_int == 2u ? 2 : 1);
+            if (sm == 0) { if (dyn) LAUNCH_S(true, 0); else LAUNCH_S(false, 0); }
+            else if (sm == 1) { if (dyn) LAUNCH_S(true, 1); else LAUNCH_S(false, 1); }
+            else { if (dyn) LAUNCH_S(true, 2); else LAUNCH_S(false, 2); }
 #undef LAUNCH_S
         } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;

@@ -933,6 +933,51 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsign
 // Takes every Philox-driven, dword-aligned step of a slip_prob == 0 handle whose pitch fits the byte arithmetic
 // (swar::fits: every golden pitch up to 11x7 does).  GENERAL = false is the steady state of an auto-resetting
 // handle (no frozen lane, no lane in a goal tuple); FULL adds final_obs and prob_code (VectorSoccerEnv).
+// Slips with a near-integer scaled threshold (slip_int == 2: 0.1, 0.9, 0.15, 0.4 ...): the integer slip decision is exact for
+// every draw except the <= 4 integers m in KernelParams::danger (probability 2^-30 each).  A thread one of whose lanes
+// drew such an m steps its four lanes one by one through lane_step — whose WORD form walks the float64 running sums for
+// exactly those draws — and hands the results back in the packed form of swar::step4, so the rest of the kernel is shared.
+__device__ __forceinline__ bool danger_hit(const KernelParams& P, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t d = P.danger[k];
+        hit |= ((w0 >> 2) == d) | ((w1 >> 2) == d) | ((w2 >> 2) == d) | ((w3 >> 2) == d);
+    }
+    return hit;
+}
+// (Inlined into the SLIPM == 2 instantiations only, whose register budget it sets: 140-200 VGPRs.  As a real call —
+// noinline, the kernels capped at 128 VGPRs — those kernels measured slower still: 8.2 vs 6.3 us per step launch.)
+__device__ __forceinline__ void slow_group4(const KernelParams& P, swar::Group& S, uint32_t aa, uint32_t ab, uint32_t w0, uint32_t w1,
+                                                      uint32_t w2, uint32_t w3, swar::Out& o) {
+    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
+    const uint32_t w[4] = {w0, w1, w2, w3};
+    swar::Group N{0u, 0u, 0u, 0u, 0u, 0u};
+    o.obs_lo = 0u; o.obs_hi = 0u; o.fin_lo = 0u; o.fin_hi = 0u; o.rew = 0u; o.term = 0u; o.trunc = 0u; o.code = 0u;
+    o.finished = 0u; o.frozen = 0u;
+    const uint32_t ca = swar::canon4(aa), cb = swar::canon4(ab);
+    o.bad_action = (ca ^ aa) | (cb ^ ab);
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t sh = 8u * (uint32_t)j;
+        Lane L;
+        L.A = make_pos((S.ra >> sh) & 0xffu, (S.ca >> sh) & 0xffu, P.W);
+        L.B = make_pos((S.rb >> sh) & 0xffu, (S.cb >> sh) & 0xffu, P.W);
+        const uint32_t psj = (S.ps >> sh) & 0xffu;
+        L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = (S.tt >> sh) & 0xffu;
+        StepResult R;
+        const bool frozen = lane_step<true, true, false>(T, P, L, (ca >> sh) & 0xffu, (cb >> sh) & 0xffu, draw_from_word(w[j]), R);
+        N.ra |= (L.A >> 24) << sh; N.ca |= ((L.A >> 16) & 0xffu) << sh;
+        N.rb |= (L.B >> 24) << sh; N.cb |= ((L.B >> 16) & 0xffu) << sh;
+        N.ps |= (L.p | (L.need << 1)) << sh; N.tt |= L.t << sh;
+        o.rew |= ((uint32_t)R.reward & 0xffu) << sh; o.term |= R.term << sh; o.trunc |= R.trunc << sh; o.code |= R.code << sh;
+        o.finished |= (R.finished ? 0x80u : 0u) << sh; o.frozen |= (frozen ? 0x80u : 0u) << sh;
+        if (j < 2) { o.obs_lo |= R.obs << (16 * j); o.fin_lo |= R.final_obs << (16 * j); }
+        else { o.obs_hi |= R.obs << (16 * (j - 2)); o.fin_hi |= R.final_obs << (16 * (j - 2)); }
+    }
+    S = N;
+}
+
 struct SwarParams {
     swar::Consts C;
     uint32_t key0, key1;
@@ -942,6 +987,7 @@ struct SwarParams {
     unsigned int* misuse;                   // [0] a frozen lane was stepped (:376), [1] an action byte outside 0..4 (:393)
     unsigned long long* hist;               // FULL: episode histogram slots (SOCCER_F_STEP_STATS), or nullptr
     swar::SlipConsts L; const swar::Quad* sub;   // SLIP: scaled cumulative weights / the nine rows of quarter thresholds
+    const KernelParams* full;               // SLIP with dangerous draws (slip_int == 2): the handle's parameters in device memory, else nullptr
     const int8_t* policy_a; const int8_t* policy_b;   // POLICY: the fixed side's int8[nS] policy (the other is nullptr)
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs;
@@ -957,7 +1003,9 @@ struct SwarParams {
 // gathered while the state loads are still in flight: they depend on the random word only), the rest stays byte-parallel.
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the observation of
 // the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
-template <bool FULL, bool SLIP = false, bool POLICY = false>
+// SLIPM: 0 slip_prob == 0; 1 the integer slip decision is exact for every draw; 2 exact except for the handle's dangerous
+// draws (slow_group4).
+template <bool FULL, int SLIPM = 0, bool POLICY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
                                                            const unsigned long long* tick_in,
@@ -999,8 +1047,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         }
         swar::Out o;
         uint32_t sa = 0u, sb = 0u, k4 = 0u, cls4 = 0u;
-        if (SLIP) swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
-        swar::step4<true, FULL, SLIP>(Q.C, S, aa, ab, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        constexpr bool SLIP = SLIPM != 0;
+        if (SLIPM == 2 && danger_hit(*Q.full, blk.w[0], blk.w[1], blk.w[2], blk.w[3])) {      // p = 2^-28 per thread
+            slow_group4(*Q.full, S, aa, ab, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        } else {
+            if (SLIP) swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+            swar::step4<true, FULL, SLIP>(Q.C, S, aa, ab, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        }
         uint8_t* sw = const_cast<uint8_t*>(sp);
         __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
         __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(sw + state_stride));
@@ -1244,12 +1297,13 @@ struct RolloutSwar {       // everything the kernel needs, and nothing else (Ker
     const int8_t* policy_a; const int8_t* policy_b;
     uint32_t key0, key1;
     swar::Consts C; swar::SlipConsts L; const swar::Quad* sub;
+    const KernelParams* full;               // slip_int == 2 handles: see slow_group4
     int32_t nS; int32_t lds_tables;
 };
 
 // the T steps of one thread's four lanes.  GENERAL = false: no lane is frozen or in a goal tuple on entry and the handle
 // auto-resets, so none ever will be (the steady state): the step's code for those cases is compiled out.
-template <bool DYN, bool SLIP, bool GENERAL>
+template <bool DYN, int SLIPM, bool GENERAL>
 __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const swar::Quad* sub,
                                                    const uint2* mix_a, const uint2* mix_b, const int8_t* pol_a, const int8_t* pol_b,
                                                    unsigned long long i0, unsigned long long tick0, swar::Group& S,
@@ -1304,8 +1358,13 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         }
         swar::Out o;
         uint32_t sa = 0u, sb = 0u, k4 = 0u, cls4 = 0u;
-        if (SLIP) swar::slip_select4(R.L, sub, swar::canon4(a4), swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
-        swar::step4<GENERAL, false, SLIP>(R.C, S, a4, b4, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        constexpr bool SLIP = SLIPM != 0;
+        if (SLIPM == 2 && danger_hit(*R.full, blk.w[0], blk.w[1], blk.w[2], blk.w[3])) {
+            slow_group4(*R.full, S, a4, b4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        } else {
+            if (SLIP) swar::slip_select4(R.L, sub, swar::canon4(a4), swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+            swar::step4<GENERAL, false, SLIP>(R.C, S, a4, b4, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        }
         s_lo = o.obs_lo; s_hi = o.obs_hi;
         const long long off = (long long)s * IO.out_stride + (long long)i0;
         if (IO.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
@@ -1329,8 +1388,9 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     }
 }
 
-template <bool DYN, bool SLIP>
+template <bool DYN, int SLIPM>
 __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar R, const RolloutIO IO) {
+    constexpr bool SLIP = SLIPM != 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     HistAcc<false> hist; hist.init_at(R.hist);
     // LDS: [0, 36) the nine threshold rows (SLIP), then (DYN, when they fit) mix_a, mix_b rows (8 B per state) and the
@@ -1370,8 +1430,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
         const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
         const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
-        if (special) rollout_swar_group<DYN, SLIP, true>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
-        else rollout_swar_group<DYN, SLIP, false>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        if (special) rollout_swar_group<DYN, SLIPM, true>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYN, SLIPM, false>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
         uint8_t* sw = R.state + i0;
         *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
         *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;

@@ -21,8 +21,9 @@ struct SlipTables {
     uint32_t slip_int;           // 0: float64 only; 1: the integer decision is exact for every draw; 2: exact except for draws in `danger`
     uint32_t danger[4];
     uint32_t c_off;              // id of the first active combination when they are consecutive (0, or 5 when slip_prob == 1)
-    bool swar_ok;                // the byte-parallel kernels may use the integer decision: slip_int == 1, the active
-                                 // combinations are consecutive ids, and every mid-point threshold equals the second quarter point
+    bool swar_ok;                // the byte-parallel kernels may use the integer decision: slip_int == 1 (or 2: then a thread that
+                                 // draws a dangerous integer leaves the byte-parallel path for that step), the active combinations are
+                                 // consecutive ids, and every mid-point threshold equals the second quarter point
 };
 
 inline SlipTables build_slip_tables(double slip_prob) {
@@ -108,9 +109,15 @@ inline SlipTables build_slip_tables(double slip_prob) {
     bool consecutive = T.nb >= 1;
     T.c_off = (uint32_t)(T.act_pack & 0xf);
     for (uint32_t i = 0; i < T.nb; ++i) consecutive = consecutive && ((T.act_pack >> (4 * i)) & 0xf) == T.c_off + i;
+    // mid-point == second quarter point, or they differ by one around a dangerous integer (then the only draw that tells
+    // them apart is that integer, which never takes the integer decision)
+    auto is_danger = [&](uint32_t m) { bool d = false; for (int q = 0; q < 4; ++q) d = d || T.danger[q] == m; return d; };
     bool mid = true;
-    for (uint32_t i = 0; i < T.nb; ++i) mid = mid && T.sub[i].x == T.sub[i].z;
-    T.swar_ok = T.slip_int == 1u && consecutive && mid;
+    for (uint32_t i = 0; i < T.nb; ++i) {
+        const uint32_t x = T.sub[i].x, z = T.sub[i].z;
+        mid = mid && (x == z || (x + 1 == z && is_danger(x)) || (z + 1 == x && is_danger(z)));
+    }
+    T.swar_ok = (T.slip_int == 1u || T.slip_int == 2u) && consecutive && mid;
     return T;
 }
 

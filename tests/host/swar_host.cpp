@@ -18,11 +18,12 @@ static void st4(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
 // slip_prob > 0: the combination and the quarter are selected from the words by swar::slip_select4 with the tables of
 // soccer_slip.hpp (what soccer_create builds).
 // Returns 0, -1 when the pitch does not qualify for the byte-parallel path, -3 when the slip does not.
+// danger[n / 4]: groups that drew one of the handle's dangerous integers (slip_int == 2), see below.
 extern "C" int swar_step_host(int width, int height, int max_steps, int autoreset, int general, int full, long n,
                               uint8_t* ra, uint8_t* ca, uint8_t* rb, uint8_t* cb, uint8_t* ps, uint8_t* tt,
                               const uint8_t* act_a, const uint8_t* act_b, const uint32_t* words, double slip_prob,
                               uint16_t* obs, uint16_t* final_obs, uint8_t* rew, uint8_t* term, uint8_t* trunc,
-                              uint8_t* code, uint8_t* finished, uint8_t* frozen, uint8_t* bad) {
+                              uint8_t* code, uint8_t* finished, uint8_t* frozen, uint8_t* bad, uint8_t* danger) {
     Rules R;
     if (!R.build(width, height).empty()) return -2;
     if (!swar::fits(R.H, R.W, max_steps)) return -1;
@@ -58,6 +59,11 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
         st4(rew + i, o.rew); st4(term + i, o.term); st4(trunc + i, o.trunc);
         st4(finished + i, (o.finished >> 7) & 0x01010101u); st4(frozen + i, (o.frozen >> 7) & 0x01010101u);
         bad[i >> 2] = o.bad_action != 0u;
+        // slip_int == 2: a group one of whose lanes drew a dangerous integer leaves the byte-parallel path in the kernels
+        // (slow_group4: float64 walk); here it is only reported, the caller leaves it out of the comparison
+        uint8_t hit = 0;
+        if (slip) for (int q = 0; q < 4; ++q) for (int j = 0; j < 4; ++j) hit |= (w[j] >> 2) == ST.danger[q];
+        danger[i >> 2] = hit;
     }
     return 0;
 }

@@ -205,15 +205,16 @@ def _reachable(b, o):
     assert (kind[(((ra * o.W + ca) * o.H + rb) * o.W + cb) * 2 + p] != 0).all()
 
 
-@pytest.mark.parametrize("path", ["swar_lean", "swar_full", "generic", "hot_slip_0p1", "rollout_swar", "rollout_fallback"])
+@pytest.mark.parametrize("path", ["swar_lean", "swar_full", "generic", "swar_slip_0p1", "hot_max_steps_200", "rollout_swar", "rollout_fallback"])
 def test_bad_action_bytes_on_device_paths_stay_inside_the_tables_and_are_flagged(path, monkeypatch):
     n, T = 8192, 30
-    slip = 0.1 if path == "hot_slip_0p1" else 0.0
+    slip = 0.1 if path == "swar_slip_0p1" else 0.0
+    ms = 200 if path == "hot_max_steps_200" else 100          # max_steps > 127 does not fit the byte arithmetic: per-lane hot kernel
     if path == "rollout_fallback":
         monkeypatch.setenv("SOCCER_ROLLOUT", "1")
     rng = np.random.default_rng(6)
-    b = SoccerBatch(n, 5, 4, slip, seed=1, autoreset=True, step_stats=False)
-    o = Oracle(5, 4, slip, n=n, seed=1, autoreset=True)
+    b = SoccerBatch(n, 5, 4, slip, seed=1, autoreset=True, step_stats=False, max_steps=ms)
+    o = Oracle(5, 4, slip, n=n, seed=1, autoreset=True, max_steps=ms)
     b.reset()
     acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
     poison = rng.random((T, 2, n)) < 0.02
@@ -237,14 +238,31 @@ def test_bad_action_bytes_on_device_paths_stay_inside_the_tables_and_are_flagged
     # the semantics: a byte executes as (byte & 7) with 5..7 -> NOOP — i.e. exactly what the oracle does on the mapped action
     canon = acts.view(np.uint8) & 7
     canon[canon > 4] = 0
-    b2 = SoccerBatch(n, 5, 4, slip, seed=1, autoreset=True, step_stats=False); b2.reset(); o.reset()
+    o.reset()
     for k in range(T):
         c = o.step(canon[k, 0].astype(np.int8), canon[k, 1].astype(np.int8))
         np.testing.assert_array_equal(O[k], c["obs"], err_msg="step %d" % k)
     _state_equal(b, o)
     b.reset_stats()
     assert b.stats()[1] == 0
-    b.close(); b2.close()
+    b.close()
+
+
+@pytest.mark.parametrize("w,h,slip,ms", [(13, 9, 0.0, 100), (13, 9, 0.2, 100), (5, 4, 0.0, 200), (5, 4, 0.2, 250)])
+def test_handles_beyond_the_byte_arithmetic_take_the_per_lane_kernels(w, h, slip, ms):
+    """H * W > 128 (13x9: 9 x 15 = 135 cells) or max_steps > 127: step_kernel_hot / rollout_kernel through the rule tables"""
+    n, steps, T = 8192, 60, 60
+    rng = np.random.default_rng(w + ms)
+    b = SoccerBatch(n, w, h, slip, seed=5, autoreset=True, max_steps=ms, step_stats=False)
+    o = Oracle(w, h, slip, n=n, seed=5, autoreset=True, max_steps=ms)
+    io = _IO(b, False)
+    b.reset(); o.reset()
+    for k in range(steps):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        _check(io.step(a[0], a[1]), o.step(a[0], a[1]), k)
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    _rollout_vs_oracle(b, o, acts, T, n)
+    b.close()
 
 
 def test_bad_actions_on_host_paths_are_refused_before_any_launch():

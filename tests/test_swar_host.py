@@ -23,7 +23,7 @@ def host(tmp_path_factory):
                            os.path.join(ROOT, "tests", "host", "swar_host.cpp")])
     L = C.CDLL(so)
     L.swar_step_host.restype = C.c_int
-    L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 9
+    L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 10
     return L
 
 
@@ -46,13 +46,15 @@ def _run_swar(L, w, h, max_steps, autoreset, general, full, st, t, need, aa, ab,
     tt = np.ascontiguousarray(t, np.uint8)
     out = dict(obs=np.zeros(n, np.uint16), final_obs=np.zeros(n, np.uint16), reward=np.zeros(n, np.uint8),
                terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), prob_code=np.zeros(n, np.uint8),
-               finished=np.zeros(n, np.uint8), frozen=np.zeros(n, np.uint8), bad=np.zeros(n // 4, np.uint8))
+               finished=np.zeros(n, np.uint8), frozen=np.zeros(n, np.uint8), bad=np.zeros(n // 4, np.uint8),
+               danger=np.zeros(n // 4, np.uint8))
     rc = L.swar_step_host(w, h, max_steps, int(autoreset), int(general), int(full), n,
                           _p(ra), _p(ca), _p(rb), _p(cb), _p(ps), _p(tt),
                           _p(np.ascontiguousarray(aa, np.uint8)), _p(np.ascontiguousarray(ab, np.uint8)),
                           _p(np.ascontiguousarray(words, np.uint32)), float(slip),
                           _p(out["obs"]), _p(out["final_obs"]), _p(out["reward"]), _p(out["terminated"]),
-                          _p(out["truncated"]), _p(out["prob_code"]), _p(out["finished"]), _p(out["frozen"]), _p(out["bad"]))
+                          _p(out["truncated"]), _p(out["prob_code"]), _p(out["finished"]), _p(out["frozen"]), _p(out["bad"]),
+                          _p(out["danger"]))
     assert rc == 0
     out["reward"] = out["reward"].view(np.int8)
     out["state"] = (ra, ca, rb, cb, ps, tt)
@@ -90,6 +92,11 @@ def _oracle_step(w, h, max_steps, autoreset, st, t, need, aa, ab, words, slip=0.
 
 
 def _compare(got, exp, need, full):
+    keep = np.repeat(got["danger"] == 0, 4)        # groups with a dangerous draw leave the byte-parallel path in the kernels
+    if not keep.all():
+        got = {k: (tuple(x[keep] for x in v) if k == "state" else v[keep] if len(v) == len(keep) else v) for k, v in got.items()}
+        exp = {k: (tuple(x[keep] for x in v) if k == "state" else v[keep] if hasattr(v, "__len__") and len(v) == len(keep) else v) for k, v in exp.items()}
+        need = need[keep]
     for k in ("obs", "reward", "terminated", "truncated") + (("final_obs", "prob_code") if full else ()):
         bad = np.flatnonzero(got[k] != exp[k])
         assert bad.size == 0, "%s differs on %d lanes, first %d: got %s expected %s" % (k, bad.size, bad[0], got[k][bad[0]], exp[k][bad[0]])
@@ -197,7 +204,8 @@ def _slip_words(slip, n, rng):
     return ((m << 2) | rng.integers(0, 4, size=n)).astype(np.uint32)
 
 
-@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.2), (5, 4, 0.5), (5, 4, 1.0), (5, 4, 0.3), (5, 4, 0.05), (7, 5, 0.3), (11, 7, 0.2)])
+@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.2), (5, 4, 0.5), (5, 4, 1.0), (5, 4, 0.3), (5, 4, 0.05), (7, 5, 0.3), (11, 7, 0.2),
+                                      (5, 4, 0.1), (5, 4, 0.9), (5, 4, 0.15), (6, 4, 0.4)])
 def test_slip_step_every_tuple_and_action_with_draws_on_every_threshold(host, w, h, slip):
     rng = np.random.default_rng(int(slip * 100) + w)
     o = Oracle(w, h, slip, n=1)
@@ -225,16 +233,15 @@ def test_slip_step_every_tuple_and_action_with_draws_on_every_threshold(host, w,
     _compare(got, exp, need0, False)
 
 
-def test_slips_with_a_near_integer_threshold_do_not_qualify(host):
-    """0.1 / 0.9 have a scaled threshold within 2^-10 of an integer (slip_int == 2): those handles stay on the per-lane
-    kernels, which send such a draw down the float64 walk"""
-    n = 4
-    z = np.zeros(n, np.uint8)
-    for slip, rc_expected in ((0.1, -3), (0.9, -3), (0.2, 0)):
-        out16 = np.zeros(n, np.uint16)
-        rc = host.swar_step_host(5, 4, 100, 1, 1, 0, n, _p(np.full(n, 1, np.uint8)), _p(np.full(n, 2, np.uint8)),
-                                 _p(np.full(n, 2, np.uint8)), _p(np.full(n, 4, np.uint8)), _p(z.copy()), _p(z.copy()),
-                                 _p(z.copy()), _p(z.copy()), _p(np.zeros(n, np.uint32)), float(slip),
-                                 _p(out16), _p(out16.copy()), _p(z.copy()), _p(z.copy()), _p(z.copy()), _p(z.copy()),
-                                 _p(z.copy()), _p(z.copy()), _p(np.zeros(1, np.uint8)))
-        assert rc == rc_expected, (slip, rc)
+def test_dangerous_draws_are_reported_per_group(host):
+    """0.1 / 0.9 have one scaled threshold within 2^-10 of an integer (slip_int == 2): the kernels send a thread that drew
+    exactly that integer through the float64 walk (tests/test_gpu_parity.py replays such draws on the GPU); the host
+    harness reports those groups so that the comparisons above leave them out — and only them."""
+    n = 64
+    st = np.tile(np.array([[1, 2, 2, 4, 0]]), (n, 1)); z = np.zeros(n, np.int64)
+    m_danger = int(round((0.81 + 3 * 0.01125) * 2 ** 30))          # 0.84375 * 2^30, exactly an integer
+    words = np.full(n, 12345 << 2, np.uint32); words[5] = m_danger << 2; words[40] = (m_danger << 2) | 3
+    got = _run_swar(host, 5, 4, 100, True, True, False, st, z, z, z, z, words, slip=0.1)
+    assert np.flatnonzero(got["danger"]).tolist() == [1, 10]
+    got = _run_swar(host, 5, 4, 100, True, True, False, st, z, z, z, z, words, slip=0.2)
+    assert not got["danger"].any()
