@@ -261,6 +261,7 @@ def test_handles_beyond_the_byte_arithmetic_take_the_per_lane_kernels(w, h, slip
         a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
         _check(io.step(a[0], a[1]), o.step(a[0], a[1]), k)
     acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    b.reset_stats(); o.hist[:] = 0                   # the single steps above did not feed the histogram (step_stats off)
     _rollout_vs_oracle(b, o, acts, T, n)
     b.close()
 
