@@ -358,9 +358,24 @@ extern "C" int batched_reset(soccer_handle* h, const uint8_t* mask, const double
     KernelParams P = h->P;
     bind_tick(h, P, 1);
     ResetIO io{mask, u_reset, obs};
-    const int grid = grid_for(h, P.n);
-    if (h->lut_lds) hipLaunchKernelGGL(reset_kernel<true>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, P, io);
-    else hipLaunchKernelGGL(reset_kernel<false>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, P, io);
+    // the byte-parallel kernel over the 4-aligned part (Philox draws, dword-aligned streams); whatever is left — a ragged
+    // tail, or everything — through the per-lane kernel on the same tick
+    unsigned long long n4 = 0;
+    if (h->swar_ok && !u_reset && h->E != 1 && (P.lane_offset & 3ull) == 0ull && aligned(mask, 4) && aligned(obs, 8)) n4 = P.n & ~3ull;
+    if (n4) {
+        ResetSwar RS{h->swar_c, P.state, P.state_stride, n4, P.lane_offset, P.tick_in, P.tick_out, P.key0, P.key1, mask, obs};
+        const dim3 g(static_cast<unsigned>(((n4 >> 2) + kBlock - 1) / kBlock)), b(kBlock);
+        if (mask) hipLaunchKernelGGL(reset_kernel_swar<true>, g, b, 0, h->stream, RS);
+        else hipLaunchKernelGGL(reset_kernel_swar<false>, g, b, 0, h->stream, RS);
+    }
+    if (n4 < P.n) {
+        KernelParams Q = P;
+        Q.first = n4; Q.n = P.n - n4;
+        if (n4) Q.tick_out = nullptr;           // the main launch publishes the tick
+        const int grid = grid_for(h, Q.n);
+        if (h->lut_lds) hipLaunchKernelGGL(reset_kernel<true>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io);
+        else hipLaunchKernelGGL(reset_kernel<false>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io);
+    }
     HIP_TRY(h, hipGetLastError());
     return SOCCER_OK;
 }

@@ -1089,9 +1089,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KernelParams P, con
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const Tables T = stage_tables<LUT_LDS>(P, smem);
     const unsigned long long tick = *P.tick_in;
-    publish_tick(P, tick, 1ull);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < P.n;
-         i += (unsigned long long)gridDim.x * kBlock) {
+    if (P.tick_out) publish_tick(P, tick, 1ull);
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < P.n;
+         k += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long i = P.first + k;                   // the launch covers lanes [first, first + n)
         const bool sel = IO.mask == nullptr || IO.mask[i] != 0;
         uint32_t ob = 0u;
         if (sel) {
@@ -1106,6 +1107,42 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KernelParams P, con
         }
         if (IO.obs) IO.obs[i] = (uint16_t)ob;
     }
+}
+
+// batched_reset, byte-parallel (Philox draws, dword-aligned streams, pitches that fit the byte arithmetic): four lanes per
+// thread, 6 dword stores + one 8-byte observation store; MASKED also reads the six state dwords and the mask dword.
+struct ResetSwar {
+    swar::Consts C;
+    uint8_t* state; unsigned long long state_stride;
+    unsigned long long n, lane_offset;
+    const unsigned long long* tick_in; unsigned long long* tick_out;
+    uint32_t key0, key1;
+    const uint8_t* mask; uint16_t* obs;
+};
+template <bool MASKED>
+__global__ __launch_bounds__(kBlock) void reset_kernel_swar(const ResetSwar R) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    const unsigned long long i0 = g << 2;
+    if (i0 >= R.n) return;                                          // n is a multiple of 4 here; the first lane is 0
+    uint8_t* sp = R.state + i0;
+    swar::Group S{0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t mask4 = 0u;
+    if (MASKED) {
+        S.ra = *reinterpret_cast<const uint32_t*>(sp); S.ca = *reinterpret_cast<const uint32_t*>(sp + R.state_stride);
+        S.rb = *reinterpret_cast<const uint32_t*>(sp + 2 * R.state_stride); S.cb = *reinterpret_cast<const uint32_t*>(sp + 3 * R.state_stride);
+        S.ps = *reinterpret_cast<const uint32_t*>(sp + 4 * R.state_stride); S.tt = *reinterpret_cast<const uint32_t*>(sp + 5 * R.state_stride);
+        mask4 = *reinterpret_cast<const uint32_t*>(R.mask + i0);
+    }
+    const unsigned long long tick = *R.tick_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *R.tick_out = tick + 1ull;
+    const unsigned long long q = (R.lane_offset + i0) >> 2;
+    const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
+    uint32_t o_lo, o_hi;
+    swar::reset4<MASKED>(R.C, S, mask4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o_lo, o_hi);
+    *reinterpret_cast<uint32_t*>(sp) = S.ra; *reinterpret_cast<uint32_t*>(sp + R.state_stride) = S.ca;
+    *reinterpret_cast<uint32_t*>(sp + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sp + 3 * R.state_stride) = S.cb;
+    *reinterpret_cast<uint32_t*>(sp + 4 * R.state_stride) = S.ps; *reinterpret_cast<uint32_t*>(sp + 5 * R.state_stride) = S.tt;
+    if (R.obs) *reinterpret_cast<uint2*>(R.obs + i0) = make_uint2(o_lo, o_hi);
 }
 
 // =================================================================================================

@@ -273,6 +273,28 @@ SOCCER_HD void obs4(const Consts& C, uint32_t r_a, uint32_t c_a, uint32_t r_b, u
     }
 }
 
+// reset (:410-424) of four lanes: every lane (MASKED = false: nothing is read) or the lanes whose mask byte is non-zero.
+// The ISD entry is drawn with the two low bits of the lane's random word, as in the in-step reset; lanes that are not
+// selected keep their state and report the observation of the tuple they hold (goal tuples: 0).
+template <bool MASKED>
+SOCCER_HD void reset4(const Consts& C, Group& S, uint32_t mask4, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                      uint32_t& obs_lo, uint32_t& obs_hi) {
+    const uint32_t y01 = perm(w1, w0, 0x0c0c0400u), y23 = perm(w3, w2, 0x0c0c0400u);
+    const uint32_t idx = (perm(y23, y01, 0x05040100u) >> C.isd_shift) & C.isd_mask;
+    const uint32_t ira = perm(0u, C.isd_ra, idx), irb = perm(0u, C.isd_rb, idx), ip = perm(0u, C.isd_p, idx);
+    uint32_t zero7 = 0u;
+    if (MASKED) {
+        const uint32_t m = mask_of(((mask4 & K7F) + K7F) | mask4);         // byte != 0
+        S.ra = bfi(m, ira, S.ra); S.ca = bfi(m, C.isd_ca4, S.ca); S.rb = bfi(m, irb, S.rb); S.cb = bfi(m, C.isd_cb4, S.cb);
+        S.ps = bfi(m, ip, S.ps); S.tt = bfi(m, 0u, S.tt);                  // needs_reset cleared, timestep 0 (:422-423)
+        const uint32_t cc = bfi(mask_of(S.ps << 7), S.cb, S.ca);
+        zero7 = is_zero(cc) | is_zero(cc ^ C.Wm1x4);
+    } else {
+        S.ra = ira; S.ca = C.isd_ca4; S.rb = irb; S.cb = C.isd_cb4; S.ps = ip; S.tt = 0u;
+    }
+    obs4<MASKED>(C, S.ra, S.ca, S.rb, S.cb, S.ps & K01, zero7, obs_lo, obs_hi);
+}
+
 // GENERAL = false: the steady state of an auto-resetting handle — no lane is frozen or stands in a goal tuple on
 //   entry (so none ever will): the code for those cases is compiled out.  The host tracks when that holds.
 // FULL: also produce final_obs and prob_code (VectorSoccerEnv's info / final_observation).

@@ -67,3 +67,22 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
     }
     return 0;
 }
+
+// batched_reset of the byte-parallel kernel: mask nullable (all lanes); words as above (reset draw = word & 3)
+extern "C" int swar_reset_host(int width, int height, long n, uint8_t* ra, uint8_t* ca, uint8_t* rb, uint8_t* cb, uint8_t* ps,
+                               uint8_t* tt, const uint8_t* mask, const uint32_t* words, uint16_t* obs) {
+    Rules R;
+    if (!R.build(width, height).empty()) return -2;
+    if (!swar::fits(R.H, R.W, 100)) return -1;
+    const swar::Consts C = swar::make_consts(R.H, R.W, R.goal_lo, R.goal_hi, 100, R.n_isd, R.isd, true);
+    for (long i = 0; i < n; i += 4) {
+        swar::Group S{ld4(ra + i), ld4(ca + i), ld4(rb + i), ld4(cb + i), ld4(ps + i), ld4(tt + i)};
+        uint32_t lo, hi;
+        const uint32_t* w = words + i;
+        if (mask) swar::reset4<true>(C, S, ld4(mask + i), w[0], w[1], w[2], w[3], lo, hi);
+        else swar::reset4<false>(C, S, 0u, w[0], w[1], w[2], w[3], lo, hi);
+        st4(ra + i, S.ra); st4(ca + i, S.ca); st4(rb + i, S.rb); st4(cb + i, S.cb); st4(ps + i, S.ps); st4(tt + i, S.tt);
+        obs[i] = (uint16_t)lo; obs[i + 1] = (uint16_t)(lo >> 16); obs[i + 2] = (uint16_t)hi; obs[i + 3] = (uint16_t)(hi >> 16);
+    }
+    return 0;
+}

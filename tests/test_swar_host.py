@@ -24,6 +24,8 @@ def host(tmp_path_factory):
     L = C.CDLL(so)
     L.swar_step_host.restype = C.c_int
     L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 10
+    L.swar_reset_host.restype = C.c_int
+    L.swar_reset_host.argtypes = [C.c_int, C.c_int, C.c_long] + [C.c_void_p] * 9
     return L
 
 
@@ -245,3 +247,30 @@ def test_dangerous_draws_are_reported_per_group(host):
     assert np.flatnonzero(got["danger"]).tolist() == [1, 10]
     got = _run_swar(host, 5, 4, 100, True, True, False, st, z, z, z, z, words, slip=0.2)
     assert not got["danger"].any()
+
+
+@pytest.mark.parametrize("w,h", PITCHES)
+def test_reset_all_lanes_and_masked(host, w, h):
+    """batched_reset's byte-parallel form: every lane, and masked (mask bytes 0 / 1 / 255 / 128) over every reachable tuple
+    incl. goal tuples and frozen lanes — state, needs_reset, timestep and the observation of every lane vs the oracle"""
+    rng = np.random.default_rng(w)
+    o = Oracle(w, h, 0.0, n=1)
+    tup = _tuples(o, [1, 2])
+    reps = 8
+    st = np.repeat(tup, reps, axis=0)
+    n = len(st) - len(st) % 4
+    st = st[:n]
+    words = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    words = (words & ~np.uint32(3)) | (np.arange(n) % 4).astype(np.uint32)
+    t = rng.integers(0, 101, size=n); need = rng.integers(0, 2, size=n)
+    for mask in (None, np.array([0, 1, 255, 128, 0, 0, 2, 0], np.uint8)[rng.integers(0, 8, size=n)]):
+        oo = Oracle(w, h, 0.0, n=n)
+        oo.set_state(st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], t=t, needs_reset=need)
+        exp = oo.reset(mask=mask, u_reset=(words & 3).astype(np.float64) * 0.25)
+        ra, ca, rb, cb = (np.ascontiguousarray(st[:, k], np.uint8) for k in range(4))
+        ps = np.ascontiguousarray(st[:, 4] | (need << 1), np.uint8); tt = np.ascontiguousarray(t, np.uint8)
+        obs = np.zeros(n, np.uint16)
+        assert host.swar_reset_host(w, h, n, _p(ra), _p(ca), _p(rb), _p(cb), _p(ps), _p(tt), _p(mask), _p(words), _p(obs)) == 0
+        np.testing.assert_array_equal(obs, exp)
+        for got, ref in ((ra, oo.row_a), (ca, oo.col_a), (rb, oo.row_b), (cb, oo.col_b), (ps, oo.poss), (tt, oo.t)):
+            np.testing.assert_array_equal(got, ref.view(np.uint8))
