@@ -140,3 +140,27 @@ def test_install_as_gym_soccer_aliases_the_reference_import_names():
     finally:
         for k in [k for k in sys.modules if k == "gym_soccer" or k.startswith("gym_soccer.")]:
             del sys.modules[k]
+
+
+def test_lazy_result_dicts_of_the_device_vector_env():
+    """VectorSoccerEnv(io="device") hands out dicts whose expensive values (float32 rewards, info["p"],
+    "_final_observation") are computed on first access and forgotten at the next step — plain-dict behaviour otherwise."""
+    from gym_soccer_littman94_amd.envs.vector_env import _Lazy, _LazyInfo
+    calls = []
+    src = {"v": 1}
+    d = _Lazy({"player_a": lambda: calls.append("a") or src["v"], "player_b": lambda: calls.append("b") or -src["v"]})
+    assert isinstance(d, dict) and "player_a" in d and "nobody" not in d and len(d) == 2 and list(d) == ["player_a", "player_b"]
+    assert calls == []
+    assert d["player_a"] == 1 and d["player_a"] == 1 and calls == ["a"]              # computed once, then cached
+    assert d.get("player_b") == -1 and d.get("nobody", 7) == 7
+    assert dict(d.items()) == {"player_a": 1, "player_b": -1} and sorted(d.values()) == [-1, 1]
+    src["v"] = 5; d.invalidate()
+    assert d["player_a"] == 5 and calls == ["a", "b", "a"]
+    with pytest.raises(KeyError):
+        d["nobody"]
+    info = _LazyInfo(lambda: "p-array")
+    top = _Lazy({"_final_observation": lambda: "mask"}, {"player_a": info, "final_observation": {"player_a": "fin"}})
+    assert set(top.keys()) == {"player_a", "final_observation", "_final_observation"}
+    assert top["player_a"]["p"] == "p-array" and top["final_observation"]["player_a"] == "fin" and top["_final_observation"] == "mask"
+    top.invalidate()
+    assert top["player_a"] is info and "_final_observation" in top
