@@ -597,10 +597,10 @@ def _rollout_vs_oracle(b, o, acts_a, acts_b, policy=None, fixed=None):
 
 @pytest.mark.parametrize("width,height,slip", [(5, 4, 0.0), (6, 4, 0.0), (7, 5, 0.0), (5, 4, 0.2), (6, 4, 0.3), (5, 4, 0.5)])
 def test_table_rollout_special_lanes_and_no_autoreset(width, height, slip):
-    """batched_rollout runs through the LDS transition table when it fits (5x4, 6x4; 7x5 falls back to the
-    rule-function kernel) and, with slip, when the handle qualifies for the integer decision (0.2, 0.3; 0.5
-    falls back): lanes frozen on entry, lanes injected into goal tuples, mixed with ordinary lanes inside one
-    thread's group of four; handles without auto-reset; a ragged lane count."""
+    """batched_rollout with lanes frozen on entry, lanes injected into goal tuples, mixed with ordinary lanes inside one
+    thread's group of four; handles without auto-reset; a ragged lane count (which sends the whole call to the per-lane
+    rollout kernel — the byte-parallel one gets the same treatment in tests/test_gpu_swar.py).  (Named after round 1's
+    LDS transition-table kernel, which the byte-parallel rollout replaced.)"""
     rng = np.random.default_rng(21)
     n, T = 4099, 130
     ot = Oracle(width, height, slip, n=1)
@@ -738,11 +738,12 @@ def test_config4_full_size_eight_shards_equal_one_handle_and_invariants():
     np.testing.assert_array_equal(S_big["t"] <= T, True)
 
 
-def test_config3_full_size_step_path_equals_rollout_path_and_oracle_on_a_shard():
+def test_config3_full_size_step_path_equals_rollout_path_and_oracle_on_a_shard(monkeypatch):
     """BASELINE config 3 at full size: 2^20 lanes x 1000 steps of uniform-random joint actions.  The single-step
-    kernel (rule functions, what bench.py times) and the fused rollout (LDS transition table) are two
-    independent implementations: every output of every lane and step must agree, and the first 4 096 lanes
-    are checked against the CPU oracle step by step (results do not depend on the sharding)."""
+    kernel (byte-parallel rules, what bench.py times) and the fused rollout — here forced onto the per-lane kernel
+    that walks the rule tables (SOCCER_ROLLOUT=1) — are two independent implementations: every output of every lane
+    and step must agree, and the first 4 096 lanes are checked against the CPU oracle step by step (results do not
+    depend on the sharding)."""
     import torch
     n, K, sub = 1 << 20, 1000, 4096
     dev = torch.device("cuda", 0)
@@ -757,7 +758,9 @@ def test_config3_full_size_step_path_equals_rollout_path_and_oracle_on_a_shard()
     for k in range(K):
         b1.step_plain(acts[k, 0], acts[k, 1], o1[0][k], o1[1][k], o1[2][k], o1[3][k])
     b1.sync()
+    monkeypatch.setenv("SOCCER_ROLLOUT", "1")             # read at soccer_create: this handle rolls out through the rule tables
     b2 = SoccerBatch(n, 5, 4, 0.0, seed=33, autoreset=True)
+    monkeypatch.delenv("SOCCER_ROLLOUT")
     b2.reset()
     o2 = bufs()
     a_flat = acts.view(K * 2, n)
@@ -819,8 +822,8 @@ def test_graph_capture_replays_advance_the_tick():
 
 @pytest.mark.parametrize("slip", [0.0, 0.2])
 def test_graph_capture_of_rollouts_and_policy_steps(slip):
-    """A captured sequence mixing two fused rollouts (LDS transition table) and two single-agent steps (hot kernel
-    with the policy lookup) replays exactly like the eager sequence on the oracle; ticks advance per replay."""
+    """A captured sequence mixing two fused rollouts and two single-agent steps (policy lookup in the kernel) replays
+    exactly like the eager sequence on the oracle; ticks advance per replay."""
     n, T = 4096, 9
     rng = np.random.default_rng(8)
     policy = rng.integers(0, 5, size=761).astype(np.int8)
