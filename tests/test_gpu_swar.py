@@ -47,7 +47,8 @@ def _check(got, exp, k):
 
 
 @pytest.mark.parametrize("w,h,slip,n", [(5, 4, 0.0, 16384 + 4), (5, 4, 0.2, 16384), (6, 4, 0.5, 8192), (7, 5, 0.3, 8192 + 8),
-                                        (9, 6, 0.0, 8192), (11, 7, 0.0, 8192), (11, 7, 0.2, 8192), (5, 4, 1.0, 4096), (5, 4, 0.05, 4096)])
+                                        (9, 6, 0.0, 8192), (11, 7, 0.0, 8192), (11, 7, 0.2, 8192), (5, 4, 1.0, 4096), (5, 4, 0.05, 4096),
+                                        (5, 4, 0.1, 8192), (7, 5, 0.9, 4096)])
 @pytest.mark.parametrize("autoreset", [True, False])
 @pytest.mark.parametrize("full", [True, False])
 def test_step_kernel_swar_every_lane_every_step(w, h, slip, n, autoreset, full):
@@ -77,7 +78,8 @@ def test_step_kernel_swar_every_lane_every_step(w, h, slip, n, autoreset, full):
     b.close()
 
 
-@pytest.mark.parametrize("w,h,slip,fixed", [(5, 4, 0.0, "player_b"), (5, 4, 0.2, "player_a"), (7, 5, 0.3, "player_b"), (11, 7, 0.0, "player_a")])
+@pytest.mark.parametrize("w,h,slip,fixed", [(5, 4, 0.0, "player_b"), (5, 4, 0.2, "player_a"), (7, 5, 0.3, "player_b"), (11, 7, 0.0, "player_a"),
+                                            (5, 4, 0.1, "player_a")])
 @pytest.mark.parametrize("full", [True, False])
 def test_step_kernel_swar_fixed_policy(w, h, slip, fixed, full):
     n, steps = 8192, 110
@@ -133,7 +135,7 @@ def _rollout_vs_oracle(b, o, acts, T, n, sample=False, mix=None):
     return ec.download(), eps
 
 
-@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (7, 5, 0.0), (9, 6, 0.0), (11, 7, 0.0), (5, 4, 0.2), (11, 7, 0.3), (6, 4, 1.0)])
+@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (7, 5, 0.0), (9, 6, 0.0), (11, 7, 0.0), (5, 4, 0.2), (11, 7, 0.3), (6, 4, 1.0), (5, 4, 0.1)])
 def test_rollout_swar_streams_every_lane_every_step(w, h, slip):
     n, T = 8192, 120
     rng = np.random.default_rng(w + int(10 * slip))
@@ -162,7 +164,7 @@ def test_rollout_swar_streams_every_lane_every_step(w, h, slip):
         b.close()
 
 
-@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (5, 4, 0.2), (11, 7, 0.0)])
+@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (5, 4, 0.2), (11, 7, 0.0), (5, 4, 0.9)])
 def test_rollout_swar_sampled_and_mixed_policies(w, h, slip):
     """in-kernel sampling: uniform, and from [nS, 4] mixed-policy thresholds — staged in LDS on 5x4, gathered from global
     memory on 11x7 (nS = 11 705 rows do not fit next to each other in 64 KB)"""
