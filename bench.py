@@ -274,9 +274,12 @@ def main():
     assert int(obs.max()) < b.nS and int(rew.abs().max()) <= 1
     if K >= 50:                     # long enough for goals to have been scored
         assert n_fin > 0 and int(rew.abs().max()) == 1, "implausible outputs"
+    gather_ms = None
     if world > 1:
+        torch.cuda.synchronize(); dist.barrier(); tg = time.perf_counter()
         gathered = gather_lane_values(last_ret.to(cdev), world * N)   # RCCL all_gather over xGMI, int8[N] per rank
         hist = np.array(reduce_histogram(hist, device=cdev))
+        torch.cuda.synchronize(); gather_ms = (time.perf_counter() - tg) * 1e3    # the job's ONLY exchange (first call: incl. RCCL set-up)
         assert gathered.numel() == world * N
     else:
         gathered = last_ret
@@ -394,7 +397,7 @@ def main():
                          "kernel": "soccer::step_kernel_swar<false, %s, false>" % ("true" if args.slip else "false"),
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
             "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
-                         "gathered_last_returns": int(gathered.numel()),
+                         "gathered_last_returns": int(gathered.numel()), "gather_allreduce_ms": gather_ms,
                          "gathered_mean": float(gathered.to(torch.float32).mean())},
         }
         if rollout:
