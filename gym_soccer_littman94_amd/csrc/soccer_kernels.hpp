@@ -1338,6 +1338,16 @@ struct RolloutSwar {       // everything the kernel needs, and nothing else (Ker
     int32_t nS; int32_t lds_tables;
 };
 
+// number of a mixed-policy row's four 16-bit cumulative thresholds (values 0..2^15) that are <= the 15-bit draw h: both
+// halves of a dword at once — (h + 0x8000) - t has bit 15 set exactly when h >= t — and one population count
+__device__ __forceinline__ uint32_t count_le15(uint32_t h, uint2 th) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t hs = __umul24(h, 0x10001u) | 0x80008000u;
+    const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, th.x));
+    const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, th.y));
+    return (uint32_t)__builtin_popcount((x & 0x80008000u) | ((y >> 1) & 0x40004000u));
+}
+
 // the T steps of one thread's four lanes.  GENERAL = false: no lane is frozen or in a goal tuple on entry and the handle
 // auto-resets, so none ever will be (the steady state): the step's code for those cases is compiled out.
 template <bool DYN, int SLIPM, bool GENERAL>
@@ -1383,10 +1393,8 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
                 if (sample) {                       // two actions from one 32-bit word, 15 bits each
                     const uint32_t ha = aw[j] & 0x7fffu, hb = (aw[j] >> 16) & 0x7fffu;
                     uint32_t a = (ha * 5u) >> 15, b = (hb * 5u) >> 15;          // uniform
-                    if (mix_a) { const uint2 th = mix_a[ob];
-                                 a = (ha >= (th.x & 0xffffu)) + (ha >= (th.x >> 16)) + (ha >= (th.y & 0xffffu)) + (ha >= (th.y >> 16)); }
-                    if (mix_b) { const uint2 th = mix_b[ob];
-                                 b = (hb >= (th.x & 0xffffu)) + (hb >= (th.x >> 16)) + (hb >= (th.y & 0xffffu)) + (hb >= (th.y >> 16)); }
+                    if (mix_a) a = count_le15(ha, mix_a[ob]);
+                    if (mix_b) b = count_le15(hb, mix_b[ob]);
                     a4 |= a << (8 * j); b4 |= b << (8 * j);
                 }
                 if (pol_a) a4 = (a4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_a[ob] << (8 * j));
