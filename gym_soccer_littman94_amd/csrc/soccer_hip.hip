@@ -537,7 +537,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                            P.policy_a, P.policy_b, P.key0, P.key1,
                            h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_params, R0.nS, 0};
             size_t smem = 36 * sizeof(uint32_t);
-            if (dyn) {
+            if (dyn && (io.mix_a || io.mix_b || P.policy_a || P.policy_b)) {
                 const size_t need = smem + 2 * (size_t)R0.nS * sizeof(uint2) + 2 * (((size_t)R0.nS + 15) & ~size_t(15));
                 if (need <= 64 * 1024) { RS.lds_tables = 1; smem = need; }
             }
@@ -548,9 +548,17 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
 #define LAUNCH_S(DV, SV) do { if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
                               hipLaunchKernelGGL((rollout_swar_kernel<DV, SV>), g, bl, smem, h->stream, RS, io); } while (0)
             const int sm = !h->slip ? 0 : (P.slip_int == 2u ? 2 : 1);
-            if (sm == 0) { if (dyn) LAUNCH_S(true, 0); else LAUNCH_S(false, 0); }
-            else if (sm == 1) { if (dyn) LAUNCH_S(true, 1); else LAUNCH_S(false, 1); }
-            else { if (dyn) LAUNCH_S(true, 2); else LAUNCH_S(false, 2); }
+            // the action source as a compile-time shape (rollout_swar_group): streams / sampled uniformly / both sides from
+            // mixed-policy tables / anything else
+            const bool fixed = P.policy_a || P.policy_b;
+            const int dm = !dyn ? 0 : (!fixed && io.sample_actions && !io.mix_a && !io.mix_b) ? 1
+                                : (!fixed && io.sample_actions && io.mix_a && io.mix_b) ? 2
+                                : (!io.sample_actions && P.policy_a && !P.policy_b && io.act_b) ? 4
+                                : (!io.sample_actions && P.policy_b && !P.policy_a && io.act_a) ? 5 : 3;
+#define LAUNCH_D(SV) do { if (dm == 0) LAUNCH_S(0, SV); else if (dm == 1) LAUNCH_S(1, SV); else if (dm == 2) LAUNCH_S(2, SV); \
+                          else if (dm == 4) LAUNCH_S(4, SV); else if (dm == 5) LAUNCH_S(5, SV); else LAUNCH_S(3, SV); } while (0)
+            if (sm == 0) LAUNCH_D(0); else if (sm == 1) LAUNCH_D(1); else LAUNCH_D(2);
+#undef LAUNCH_D
 #undef LAUNCH_S
         } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;

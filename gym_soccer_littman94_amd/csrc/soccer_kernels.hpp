@@ -1350,20 +1350,34 @@ __device__ __forceinline__ uint32_t count_le15(uint32_t h, uint2 th) {
 
 // the T steps of one thread's four lanes.  GENERAL = false: no lane is frozen or in a goal tuple on entry and the handle
 // auto-resets, so none ever will be (the steady state): the step's code for those cases is compiled out.
-template <bool DYN, int SLIPM, bool GENERAL>
+// DYNM — where the actions come from: 0 both from the action streams; 1 both sampled uniformly in the kernel; 2 both
+// sampled from mixed-policy tables (config 5); 4 / 5 player A / B follows its fixed policy and the other side's actions
+// are streamed (single-agent mode); 3 anything else (a table on one side only, a fixed policy against a sampled side ...:
+// decided by wave-uniform run-time tests).  The common shapes are instantiations of their own because every optional
+// pointer that stays live costs scalar registers, and the loop of the catch-all form spilled them (60-300 v_readlane_b32
+// per step).
+template <int DYNM, int SLIPM, bool GENERAL>
 __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const swar::Quad* sub,
-                                                   const uint2* mix_a, const uint2* mix_b, const int8_t* pol_a, const int8_t* pol_b,
+                                                   const uint2* mix_a_in, const uint2* mix_b_in, const int8_t* pol_a_in, const int8_t* pol_b_in,
                                                    unsigned long long i0, unsigned long long tick0, swar::Group& S,
                                                    uint32_t& fin_tot, uint32_t& nz_tot, uint32_t& neg_tot,
                                                    uint32_t (&acc)[4], uint32_t& frozen_any, uint32_t& bad_any) {
-    const bool sample = DYN && IO.sample_actions;
+    constexpr bool DYN = DYNM != 0;
+    const bool sample = DYNM == 1 || DYNM == 2 || (DYNM == 3 && IO.sample_actions);
+    const uint2* mix_a = DYNM == 2 || DYNM == 3 ? mix_a_in : nullptr;
+    const uint2* mix_b = DYNM == 2 || DYNM == 3 ? mix_b_in : nullptr;
+    const int8_t* pol_a = DYNM == 3 || DYNM == 4 ? pol_a_in : nullptr;
+    const int8_t* pol_b = DYNM == 3 || DYNM == 5 ? pol_b_in : nullptr;
+    const bool use_pol_a = DYNM == 4 || (DYNM == 3 && pol_a != nullptr), use_pol_b = DYNM == 5 || (DYNM == 3 && pol_b != nullptr);
+    const bool use_mix_a = DYNM == 2 || (DYNM == 3 && sample && mix_a != nullptr);
+    const bool use_mix_b = DYNM == 2 || (DYNM == 3 && sample && mix_b != nullptr);
+    const bool load_a = DYNM == 0 || DYNM == 5 || (DYNM == 3 && !sample && IO.act_a != nullptr);
+    const bool load_b = DYNM == 0 || DYNM == 4 || (DYNM == 3 && !sample && IO.act_b != nullptr);
     const bool lane_acc = IO.return_sum != nullptr || IO.episode_count != nullptr;
-    const bool by_obs = DYN && (pol_a != nullptr || pol_b != nullptr || (sample && (mix_a != nullptr || mix_b != nullptr)));
+    const bool by_obs = DYNM == 2 || DYNM == 4 || DYNM == 5 || (DYNM == 3 && (use_pol_a || use_pol_b || use_mix_a || use_mix_b));
     uint32_t aa = 0u, ab = 0u;
-    if (!sample) {
-        if (!DYN || IO.act_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
-        if (!DYN || IO.act_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
-    }
+    if (load_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
+    if (load_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
     // the observation of the current tuple (goal tuples: 0), carried along when an action depends on it
     uint32_t s_lo = 0u, s_hi = 0u;
     if (by_obs) {
@@ -1374,9 +1388,9 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     for (int s = 0; s < IO.n_steps; ++s) {
         const unsigned long long tick = tick0 + (unsigned long long)s;
         uint32_t naa = aa, nab = ab;
-        if (!sample && s + 1 < IO.n_steps) {                            // prefetch the next step's actions
-            if (!DYN || IO.act_a) naa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)(s + 1) * IO.act_stride + i0));
-            if (!DYN || IO.act_b) nab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)(s + 1) * IO.act_stride + i0));
+        if (s + 1 < IO.n_steps) {                                       // prefetch the next step's actions
+            if (load_a) naa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)(s + 1) * IO.act_stride + i0));
+            if (load_b) nab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)(s + 1) * IO.act_stride + i0));
         }
         const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
         uint32_t a4 = aa, b4 = ab;
@@ -1393,12 +1407,12 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
                 if (sample) {                       // two actions from one 32-bit word, 15 bits each
                     const uint32_t ha = aw[j] & 0x7fffu, hb = (aw[j] >> 16) & 0x7fffu;
                     uint32_t a = (ha * 5u) >> 15, b = (hb * 5u) >> 15;          // uniform
-                    if (mix_a) a = count_le15(ha, mix_a[ob]);
-                    if (mix_b) b = count_le15(hb, mix_b[ob]);
+                    if (use_mix_a) a = count_le15(ha, mix_a[ob]);
+                    if (use_mix_b) b = count_le15(hb, mix_b[ob]);
                     a4 |= a << (8 * j); b4 |= b << (8 * j);
                 }
-                if (pol_a) a4 = (a4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_a[ob] << (8 * j));
-                if (pol_b) b4 = (b4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_b[ob] << (8 * j));
+                if (use_pol_a) a4 = (a4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_a[ob] << (8 * j));
+                if (use_pol_b) b4 = (b4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_b[ob] << (8 * j));
             }
         }
         swar::Out o;
@@ -1433,9 +1447,10 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     }
 }
 
-template <bool DYN, int SLIPM>
+template <int DYNM, int SLIPM>
 __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar R, const RolloutIO IO) {
     constexpr bool SLIP = SLIPM != 0;
+    constexpr bool DYN = DYNM >= 2;          // the forms that look something up by the observation
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     HistAcc<false> hist; hist.init_at(R.hist);
     // LDS: [0, 36) the nine threshold rows (SLIP), then (DYN, when they fit) mix_a, mix_b rows (8 B per state) and the
@@ -1443,8 +1458,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
     const swar::Quad* sub = R.sub;
     const uint2* mix_a = reinterpret_cast<const uint2*>(IO.mix_a);
     const uint2* mix_b = reinterpret_cast<const uint2*>(IO.mix_b);
-    const int8_t* pol_a = R.policy_a; const int8_t* pol_b = R.policy_b;
-    const bool sample = DYN && IO.sample_actions;
+    const int8_t* pol_a = DYNM == 3 || DYNM == 4 ? R.policy_a : nullptr; const int8_t* pol_b = DYNM == 3 || DYNM == 5 ? R.policy_b : nullptr;
+    const bool sample = DYNM == 2 || (DYNM == 3 && IO.sample_actions);
     if (SLIP || (DYN && R.lds_tables)) {
         if (SLIP) { if (threadIdx.x < 36) smem[threadIdx.x] = reinterpret_cast<const uint32_t*>(R.sub)[threadIdx.x];
                     sub = reinterpret_cast<const swar::Quad*>(smem); }
@@ -1475,8 +1490,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
         const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
         const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
-        if (special) rollout_swar_group<DYN, SLIPM, true>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
-        else rollout_swar_group<DYN, SLIPM, false>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        if (special) rollout_swar_group<DYNM, SLIPM, true>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYNM, SLIPM, false>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
         uint8_t* sw = R.state + i0;
         *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
         *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;

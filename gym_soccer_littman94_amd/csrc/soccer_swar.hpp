@@ -110,6 +110,9 @@ struct Consts {
     uint32_t row_lo, row_hi;
     uint32_t col_lut;                 // != 0: W <= 8, col_lo / col_hi[c] = clamp(c, 1, W - 2): a step into a goal column undone
     uint32_t col_lo, col_hi;
+    uint32_t grow_lo, grow_hi;        // row_lut: flag byte 0x80 for the goal rows (:60)
+    uint32_t rew_lo, rew_hi;          // col_lut: player A's reward by the carrier's column: 0xff at column 0, 0x01 at W - 1 (:237-240)
+    uint32_t term_lo, term_hi;        // col_lut: 0x01 at the two goal columns
 };
 
 // A pitch qualifies when every byte quantity stays below 128 (bit 7 is the guard bit):
@@ -155,6 +158,16 @@ inline Consts make_consts(int H, int W, int goal_lo, int goal_hi, int max_steps,
     if (C.row_lut) table(H + 2, 0, H - 1, 1, C.row_lo, C.row_hi);
     C.col_lut = W <= 8 ? 1u : 0u;
     if (C.col_lut) table(W, 1, W - 2, 0, C.col_lo, C.col_hi);
+    auto flags = [](int n, auto f, uint32_t& tlo, uint32_t& thi) {
+        uint64_t t = 0;
+        for (int u = 0; u < 8 && u < n; ++u) t |= (uint64_t)(uint8_t)f(u) << (8 * u);
+        tlo = (uint32_t)t; thi = (uint32_t)(t >> 32);
+    };
+    if (C.row_lut) flags(H, [&](int r) { return r >= goal_lo && r <= goal_hi ? 0x80 : 0; }, C.grow_lo, C.grow_hi);
+    if (C.col_lut) {
+        flags(W, [&](int c) { return c == 0 ? 0xff : (c == W - 1 ? 0x01 : 0); }, C.rew_lo, C.rew_hi);
+        flags(W, [&](int c) { return c == 0 || c == W - 1 ? 0x01 : 0; }, C.term_lo, C.term_hi);
+    }
     return C;
 }
 
@@ -326,8 +339,9 @@ SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw
     }
     if (!SLIP) { sa = aa; sb = ab; } else { sa &= 0x07070707u; sb &= 0x07070707u; }
     // ---- tentative cells (:307-312) ---------------------------------------------------------------------------------
-    const uint32_t gra = bfi(ra + C.gr_hi_add, 0u, ra + C.gr_lo_add);     // flag: row in the goal rows
-    const uint32_t grb = bfi(rb + C.gr_hi_add, 0u, rb + C.gr_lo_add);
+    uint32_t gra, grb;                                                     // flag: row in the goal rows
+    if (C.row_lut) { gra = perm(C.grow_hi, C.grow_lo, ra); grb = perm(C.grow_hi, C.grow_lo, rb); }
+    else { gra = bfi(ra + C.gr_hi_add, 0u, ra + C.gr_lo_add); grb = bfi(rb + C.gr_hi_add, 0u, rb + C.gr_lo_add); }
     uint32_t nra, nca, nrb, ncb;
     move4(C, ra, ca, sa, bfi(p7, 0u, gra), nra, nca);                      // A holds the ball when p == 0
     move4(C, rb, cb, sb, grb & p7, nrb, ncb);
@@ -364,15 +378,19 @@ SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw
     // ---- done / reward (:235-240), bookkeeping (:399-406) -------------------------------------------------------------
     const uint32_t pmn = mask_of(p7n);
     const uint32_t cc = bfi(pmn, fcb, fca);                                // the carrier's column after the step
-    const uint32_t g0 = is_zero(cc), gW = is_zero(cc ^ C.Wm1x4);
-    const uint32_t goal7 = g0 | gW;
-    uint32_t rew = one_of(gW) | mask_of(g0);                               // +1 into B's goal line, -1 (0xff) into A's
+    uint32_t goal7, rew, term01;                                           // +1 into B's goal line, -1 (0xff) into A's
+    if (C.col_lut) {
+        rew = perm(C.rew_hi, C.rew_lo, cc); term01 = perm(C.term_hi, C.term_lo, cc); goal7 = term01 << 7;
+    } else {
+        const uint32_t g0 = is_zero(cc), gW = is_zero(cc ^ C.Wm1x4);
+        goal7 = g0 | gW; rew = one_of(gW) | mask_of(g0); term01 = one_of(goal7);
+    }
     if (GENERAL) rew = bfi(hold_m, 0u, rew);                               // from a goal tuple: reward 0 (:235-236)
     uint32_t tt = t + (GENERAL ? bfi(frz_m, 0u, K01) : K01);               // :399 (a frozen lane keeps its timestep)
     const uint32_t trunc7 = tt + C.trunc_add;                              // :404
     const uint32_t need7 = goal7 | trunc7;                                 // :406
     const uint32_t fin7 = GENERAL ? bfi(frz7, 0u, need7) : need7;          // episodes that ended at this step
-    o.rew = rew; o.term = one_of(goal7); o.trunc = one_of(trunc7);
+    o.rew = rew; o.term = term01; o.trunc = one_of(trunc7);
     o.finished = fin7; o.frozen = frz7 & K80;
     if (FULL) {
         // outcome class of the sampled entry: 0 single, 1 one of two, 2 one of four; slip class from the caller
