@@ -10,12 +10,19 @@ shutil.copy(ks, 'profiles/%s_kernel_stats.csv' % tag)
 for r in csv.DictReader(open(ks)):
     if 'soccer::' in r['Name']:
         print("%-100s calls %5s avg %10.1f min %8s max %8s" % (r['Name'][:100], r['Calls'], float(r['AverageNs']), r['MinNs'], r['MaxNs']))
+full = glob.glob(src + '/kt_full/runc/*_kernel_stats.csv') + glob.glob(src + '/kt_full/*kernel_stats.csv')
+if full:
+    shutil.copy(full[0], 'profiles/%s_kernel_stats_full.csv' % tag)
+    print("-- default command (kt_full):")
+    for r in csv.DictReader(open(full[0])):
+        if 'soccer::' in r['Name']:
+            print("%-100s calls %5s avg %10.1f min %8s max %8s" % (r['Name'][:100], r['Calls'], float(r['AverageNs']), r['MinNs'], r['MaxNs']))
+    fl = open(src + '/bench_full.json').read().strip().split('\n')[-1]
+    open('profiles/%s_bench_full.json' % tag, 'w').write(fl + '\n')
 line = open(src + '/bench.json').read().strip().split('\n')[-1]
 open('profiles/%s_bench.json' % tag, 'w').write(line + '\n')
 d = json.loads(line)
-print("bench (profiled run): value %.4g launch_us %.3f frac %.4f rollout %.4g selfplay %.4g" % (
-    d['value'], d['roofline']['launch_us'], d['roofline']['frac'], d.get('fused_rollout', {}).get('env_steps_per_s', 0),
-    d.get('selfplay_rollout_config5', {}).get('env_steps_per_s', 0)))
+print("bench (profiled run, kt): value %.4g launch_us %.3f frac %.4f" % (d['value'], d['roofline']['launch_us'], d['roofline']['frac']))
 import os as _os
 for extra in ('bench_unprofiled.json', 'bench_driver_shape.json'):
     if _os.path.exists(src + '/' + extra):

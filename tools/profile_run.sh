@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun): the rocprofv3 passes behind profiles/<tag>_*.  Usage: tools/profile_run.sh r02_a
-#   kt     kernel trace + stats of the default bench command (timing; the bench line of the same run is kept)
+#   kt       kernel trace + stats of the bench's timed region (step kernel only; the bench line of the same run is kept)
+#   kt_full  the same for the default command (rollouts, self-play, VectorSoccerEnv kernels)
 #   fetch / write   FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, rocprofv3 PMC slots)
 #   sq1 / sq2       SQ instruction / wait counters
 # Counters are collected with --kernel-trace only (never with the runtime / hip trace domains).
@@ -11,8 +12,12 @@ OUT="$ROOTDIR/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOTDIR/bench.py"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o runc -- python3 "$B" --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/kt.err"
+# kt: the step kernel alone (the bench's timed region; nothing else in the process for the profiler to interleave with)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o runc -- python3 "$B" --steps 1000 --warmup 50 --no-cpu-baseline --rollout 0 --no-vector-env > "$OUT/bench.json" 2> "$OUT/kt.err"
 echo "kt done"
+# kt_full: the default command (rollouts, self-play, VectorSoccerEnv): the other kernels' durations
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_full" -o runc -- python3 "$B" --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/bench_full.json" 2> "$OUT/kt_full.err"
+echo "kt_full done"
 PMC_ARGS="--steps 100 --warmup 10 --no-cpu-baseline --rollout 20 --no-vector-env"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o runc -- python3 "$B" $PMC_ARGS > "$OUT/fetch.json" 2> "$OUT/fetch.err"
 echo "fetch done"
