@@ -390,7 +390,6 @@ static void launch_step3(soccer_handle* h, const KernelParams& P, const StepIO& 
 static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& io, bool explicit_u, bool vec) {
     const bool shared = ((P.lane_offset + P.first) & 3ull) == 0ull;
     const bool policy_only = explicit_u && !io.u_step && !io.u_reset;       // fixed-policy handle, Philox draws
-    const bool lean0 = !io.prob_code && !io.final_obs && !io.last_return && !P.step_stats;
     const bool swar_fit = vec && shared && h->swar_ok && (!h->slip || h->slip_swar_ok) && !io.last_return;
     if ((policy_only || !explicit_u) && swar_fit) {
         // the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
@@ -408,15 +407,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
 #undef SWAR_SLIP
 #undef SWAR_GO
 #undef SWAR_ARGS
-    } else if (policy_only && vec && shared && lean0) {                     // the per-lane hot kernel with the policy lookup
-        const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
-        const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
-#define HOT_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), P, io
-        if (h->slip && P.slip_int == 1u) hipLaunchKernelGGL((step_kernel_hot<true, true, true>), gh, b, 0, h->stream, HOT_ARGS);
-        else if (h->slip) hipLaunchKernelGGL((step_kernel_hot<true, false, true>), gh, b, 0, h->stream, HOT_ARGS);
-        else hipLaunchKernelGGL((step_kernel_hot<false, false, true>), gh, b, 0, h->stream, HOT_ARGS);
-#undef HOT_ARGS
-    } else if (explicit_u) {    // facade / test path: generic instantiations only
+    } else if (explicit_u) {    // caller-supplied uniforms (facade, tests) and fixed-policy handles beyond the byte arithmetic: generic kernel
         if (vec && shared) launch_step3<true, true, true>(h, P, io); else launch_step3<true, false, false>(h, P, io);
     } else if (vec && shared) {
         // the hot instantiations of the per-lane kernel (slip handles, pitches beyond the byte arithmetic);

@@ -797,9 +797,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
 // one group of 4 lanes per thread, no grid-stride loop, no fallback or optional-output code at all.
 // Same lane loop as step_kernel; kept separate because a launch starts with a cold instruction cache
 // and every instruction that is not fetched counts (-0.4 us per launch against step_kernel<..., LEAN>).
-// POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the current
-// observation (two more dependent table reads per lane); its action stream may be NULL.
-template <bool SLIP, bool INT_ONLY = false, bool POLICY = false, int UNROLL = 1>
+template <bool SLIP, bool INT_ONLY = false, int UNROLL = 1>
 __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& IO, unsigned long long g,
                                           const unsigned long long* tick_ptr, unsigned long long tick_val) {
     const unsigned long long i0 = P.first + (g << 2);
@@ -819,11 +817,11 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
 #undef SOCCER_LD
     uint32_t aa = 0u, ab = 0u;
 #ifndef SOCCER_TEMPORAL_IO
-    if (!POLICY || !P.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
-    if (!POLICY || !P.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
+    aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
+    ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
 #else
-    if (!POLICY || !P.policy_a) aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
-    if (!POLICY || !P.policy_b) ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
+    aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
+    ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
 #endif
     // action bytes execute as table[byte & 7] with 5..7 -> NOOP; anything outside 0..4 is reported (:393)
     const uint32_t aa_raw = aa, ab_raw = ab;
@@ -847,12 +845,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
         L.B = make_pos(__builtin_amdgcn_ubfe(rb, sh, 8u), __builtin_amdgcn_ubfe(cb, sh, 8u), P.W);
         L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
         StepResult R;
-        uint32_t a_now = __builtin_amdgcn_ubfe(aa, sh, 8u), b_now = __builtin_amdgcn_ubfe(ab, sh, 8u);
-        if (POLICY) {
-            const uint32_t s_now = obs_of(T, P, L.A, L.B, L.p);
-            if (P.policy_a) a_now = (uint32_t)(uint8_t)P.policy_a[s_now];
-            if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
-        }
+        const uint32_t a_now = __builtin_amdgcn_ubfe(aa, sh, 8u), b_now = __builtin_amdgcn_ubfe(ab, sh, 8u);
         mis |= lane_step<SLIP, true, INT_ONLY>(T, P, L, a_now, b_now, draw_from_word(w), R);
         if constexpr (UNROLL == 4) { posA[j] = L.A; posB[j] = L.B; }    // rows / columns gathered with v_perm after the loop
         else {
@@ -908,7 +901,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
 // the library is built with -mllvm -amdgpu-kernarg-preload-count=14, so they arrive in SGPRs at wave launch
 // and the nine data loads are issued without first waiting for a scalar load of the kernarg segment
 // (-0.3 .. -0.6 us per launch, tools/pipeline_lab.hip); the rest of P is fetched while they are in flight.
-template <bool SLIP, bool INT_ONLY = false, bool POLICY = false>
+template <bool SLIP, bool INT_ONLY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsigned long long state_stride,
                                                           const int8_t* act_a, const int8_t* act_b,
                                                           const unsigned long long* tick_in,
@@ -920,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsign
     if ((g << 2) >= n) return;                                      // n is a multiple of 4 here; the first lane is 0
     KernelParams Q = P; Q.state = state; Q.state_stride = state_stride; Q.n = n; Q.first = 0ull;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP, INT_ONLY, POLICY, SLIP ? SOCCER_HOT_UNROLL_SLIP : SOCCER_HOT_UNROLL>(Q, J, g, tick_in, tick_val);
+    hot_group<SLIP, INT_ONLY, SLIP ? SOCCER_HOT_UNROLL_SLIP : SOCCER_HOT_UNROLL>(Q, J, g, tick_in, tick_val);
 }
 
 // =================================================================================================

@@ -265,6 +265,18 @@ def test_handles_beyond_the_byte_arithmetic_take_the_per_lane_kernels(w, h, slip
     acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
     b.reset_stats(); o.hist[:] = 0                   # the single steps above did not feed the histogram (step_stats off)
     _rollout_vs_oracle(b, o, acts, T, n)
+    # single-agent mode on such a handle: the fixed side's action by the generic kernel's policy gather
+    policy = rng.integers(0, 5, size=o.nS).astype(np.int8)
+    b.set_policy("player_b", policy)
+    lut = o.tables()[0]
+    f = ((((o.row_a.astype(np.int64) * o.W + o.col_a) * o.H + o.row_b) * o.W + o.col_b) << 1) | (o.poss & 1)
+    cur = lut[f]
+    for k in range(30):
+        act = rng.integers(0, 5, size=n, dtype=np.int8)
+        c = o.step(act, policy[cur])
+        _check(io.step(act, None), c, k)
+        cur = c["obs"]
+    _state_equal(b, o)
     b.close()
 
 

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void k_plain_pre(uint8_t* state, unsigned l
     if ((g << 2) >= n) return;
     KernelParams Q = P; Q.state = state; Q.state_stride = stride; Q.n = n; Q.first = first;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP, false, false, UNROLL>(Q, J, g, nullptr, tick);
+    hot_group<SLIP, false, UNROLL>(Q, J, g, nullptr, tick);
 }
 
 template <bool SLIP, int BLOCK>
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(BLOCK) void k_plain_blk(uint8_t* state, unsigned lo
     if ((g << 2) >= n) return;
     KernelParams Q = P; Q.state = state; Q.state_stride = stride; Q.n = n; Q.first = first;
     StepIO J = IO; J.act_a = act_a; J.act_b = act_b;
-    hot_group<SLIP, false, false, 4>(Q, J, g, nullptr, tick);
+    hot_group<SLIP, false, 4>(Q, J, g, nullptr, tick);
 }
 
 // Phase-structured variant of the slip-0 hot body: all eight move-table reads of the thread's four lanes are issued
