@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (results: profiles/r02_sweep.md): the SOCCER_SWAR_* / SOCCER_FORCE_GENERAL knobs this script sets existed only
+# in commit 4aef6d3..f61d5bd's library and were removed once the sweep had picked the shipped shape.
 # A/B sweep of the byte-parallel step kernel's launch shape (run on the GPU box): lanes per thread (G x 4), store policy
 # (0 nt, 1 plain, 2 write-through), block size, steady-state vs general instantiation.  Prints HIP-event us per launch.
 cd "$(dirname "$0")/.."
