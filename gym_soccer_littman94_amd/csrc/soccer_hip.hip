@@ -400,7 +400,8 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
                      h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_params, P.policy_a, P.policy_b,
                      io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs};
 #define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
-#define SWAR_GO(FV, SV, PV) hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV>), gh, b, 0, h->stream, SWAR_ARGS)
+#define SWAR_GO(FV, SV, PV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV, 1>), gh, b, 0, h->stream, SWAR_ARGS); \
+                                 else hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV, 0>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
 #define SWAR_SLIP(FV, PV) do { if (!h->slip) SWAR_GO(FV, 0, PV); else if (P.slip_int == 2u) SWAR_GO(FV, 2, PV); else SWAR_GO(FV, 1, PV); } while (0)
         if (policy_only) { if (full) SWAR_SLIP(true, true); else SWAR_SLIP(false, true); }
         else { if (full) SWAR_SLIP(true, false); else SWAR_SLIP(false, false); }
@@ -536,8 +537,9 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             uint64_t blocks = (groups + kBlock - 1) / kBlock;
             if (blocks > (uint64_t)h->grid_cap) blocks = h->grid_cap;
             const dim3 g((unsigned)blocks), bl(kBlock);
-#define LAUNCH_S(DV, SV) do { if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-                              hipLaunchKernelGGL((rollout_swar_kernel<DV, SV>), g, bl, smem, h->stream, RS, io); } while (0)
+#define LAUNCH_G(DV, SV, GV) do { if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV, GV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+                                  hipLaunchKernelGGL((rollout_swar_kernel<DV, SV, GV>), g, bl, smem, h->stream, RS, io); } while (0)
+#define LAUNCH_S(DV, SV) do { if (h->swar_c.small) LAUNCH_G(DV, SV, 1); else LAUNCH_G(DV, SV, 0); } while (0)
             const int sm = !h->slip ? 0 : (P.slip_int == 2u ? 2 : 1);
             // the action source as a compile-time shape (rollout_swar_group): streams / sampled uniformly / both sides from
             // mixed-policy tables / anything else
@@ -551,6 +553,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             if (sm == 0) LAUNCH_D(0); else if (sm == 1) LAUNCH_D(1); else LAUNCH_D(2);
 #undef LAUNCH_D
 #undef LAUNCH_S
+#undef LAUNCH_G
         } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;
             case 4: launch_rollout<4>(h, P, io); break;

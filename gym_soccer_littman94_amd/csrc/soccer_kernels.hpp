@@ -998,7 +998,7 @@ struct SwarParams {
 // the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
 // SLIPM: 0 slip_prob == 0; 1 the integer slip decision is exact for every draw; 2 exact except for the handle's dangerous
 // draws (slow_group4).
-template <bool FULL, int SLIPM = 0, bool POLICY = false>
+template <bool FULL, int SLIPM = 0, bool POLICY = false, int GEO = 0>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
                                                            const unsigned long long* tick_in,
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
             slow_group4(*Q.full, S, aa, ab, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
         } else {
             if (SLIP) swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
-            swar::step4<true, FULL, SLIP>(Q.C, S, aa, ab, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+            swar::step4<true, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
         }
         uint8_t* sw = const_cast<uint8_t*>(sp);
         __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
@@ -1349,7 +1349,7 @@ __device__ __forceinline__ uint32_t count_le15(uint32_t h, uint2 th) {
 // decided by wave-uniform run-time tests).  The common shapes are instantiations of their own because every optional
 // pointer that stays live costs scalar registers, and the loop of the catch-all form spilled them (60-300 v_readlane_b32
 // per step).
-template <int DYNM, int SLIPM, bool GENERAL>
+template <int DYNM, int SLIPM, bool GENERAL, int GEO>
 __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const swar::Quad* sub,
                                                    const uint2* mix_a_in, const uint2* mix_b_in, const int8_t* pol_a_in, const int8_t* pol_b_in,
                                                    unsigned long long i0, unsigned long long tick0, swar::Group& S,
@@ -1415,7 +1415,7 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             slow_group4(*R.full, S, a4, b4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
         } else {
             if (SLIP) swar::slip_select4(R.L, sub, swar::canon4(a4), swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
-            swar::step4<GENERAL, false, SLIP>(R.C, S, a4, b4, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+            swar::step4<GENERAL, false, SLIP, GEO>(R.C, S, a4, b4, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
         }
         s_lo = o.obs_lo; s_hi = o.obs_hi;
         const long long off = (long long)s * IO.out_stride + (long long)i0;
@@ -1440,7 +1440,7 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     }
 }
 
-template <int DYNM, int SLIPM>
+template <int DYNM, int SLIPM, int GEO = 0>
 __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar R, const RolloutIO IO) {
     constexpr bool SLIP = SLIPM != 0;
     constexpr bool DYN = DYNM >= 2;          // the forms that look something up by the observation
@@ -1483,8 +1483,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
         const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
         const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
-        if (special) rollout_swar_group<DYNM, SLIPM, true>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
-        else rollout_swar_group<DYNM, SLIPM, false>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        if (special) rollout_swar_group<DYNM, SLIPM, true, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYNM, SLIPM, false, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
         uint8_t* sw = R.state + i0;
         *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
         *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;

@@ -19,6 +19,9 @@ static void st4(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
 // soccer_slip.hpp (what soccer_create builds).
 // Returns 0, -1 when the pitch does not qualify for the byte-parallel path, -3 when the slip does not.
 // danger[n / 4]: groups that drew one of the handle's dangerous integers (slip_int == 2), see below.
+static int geo = -1;     // -1: as the library (tables on small pitches); 0: force the arithmetic geometry
+extern "C" void swar_set_geo(int g) { geo = g; }
+
 extern "C" int swar_step_host(int width, int height, int max_steps, int autoreset, int general, int full, long n,
                               uint8_t* ra, uint8_t* ca, uint8_t* rb, uint8_t* cb, uint8_t* ps, uint8_t* tt,
                               const uint8_t* act_a, const uint8_t* act_b, const uint32_t* words, double slip_prob,
@@ -43,7 +46,9 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
         const uint32_t* w = words + i;
         uint32_t s_a = 0u, s_b = 0u, k4 = 0u, c4 = 0u;
         if (slip) swar::slip_select4(L, ST.sub, swar::canon4(a), swar::canon4(b), w[0], w[1], w[2], w[3], s_a, s_b, k4, c4);
-#define CALL(G, F, SL) swar::step4<G, F, SL>(C, S, a, b, s_a, s_b, k4, c4, w[0], w[1], w[2], w[3], o)
+        // geometry: byte tables where the pitch allows (what the library picks), arithmetic otherwise or when geo == 0 is forced
+#define CALL(G, F, SL) do { if (C.small && geo != 0) swar::step4<G, F, SL, 1>(C, S, a, b, s_a, s_b, k4, c4, w[0], w[1], w[2], w[3], o); \
+                            else swar::step4<G, F, SL, 0>(C, S, a, b, s_a, s_b, k4, c4, w[0], w[1], w[2], w[3], o); } while (0)
         if (slip) { if (general) { if (full) CALL(true, true, true); else CALL(true, false, true); }
                     else { if (full) CALL(false, true, true); else CALL(false, false, true); } }
         else { if (general) { if (full) CALL(true, true, false); else CALL(true, false, false); }

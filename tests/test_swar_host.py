@@ -114,9 +114,20 @@ def _compare(got, exp, need, full):
 PITCHES = [(5, 4), (6, 4), (7, 5), (9, 6), (11, 7)]
 
 
+@pytest.fixture(params=["tables", "arithmetic"])
+def geometry(request, host):
+    """both instantiations of the pitch geometry: byte tables (small pitches; larger ones take the arithmetic anyway)
+    and arithmetic forced on every pitch"""
+    host.swar_set_geo(-1 if request.param == "tables" else 0)
+    yield request.param
+    host.swar_set_geo(-1)
+
+
 @pytest.mark.parametrize("w,h", PITCHES)
 @pytest.mark.parametrize("autoreset", [True, False])
-def test_general_step_every_tuple_action_and_draw(host, w, h, autoreset):
+def test_general_step_every_tuple_action_and_draw(host, geometry, w, h, autoreset):
+    if geometry == "arithmetic" and (w, h) not in ((5, 4), (6, 4)):
+        pytest.skip("already arithmetic")
     rng = np.random.default_rng(w * 100 + h)
     o = Oracle(w, h, 0.0, n=1)
     tup = _tuples(o, [1, 2])                                   # live and goal tuples
@@ -130,7 +141,9 @@ def test_general_step_every_tuple_action_and_draw(host, w, h, autoreset):
 
 
 @pytest.mark.parametrize("w,h", PITCHES)
-def test_steady_state_step_every_live_tuple_action_and_draw(host, w, h):
+def test_steady_state_step_every_live_tuple_action_and_draw(host, geometry, w, h):
+    if geometry == "arithmetic" and (w, h) not in ((5, 4), (6, 4)):
+        pytest.skip("already arithmetic")
     """the instantiation of an auto-resetting handle whose lanes have all been reset: no frozen / goal-tuple code"""
     rng = np.random.default_rng(w * 100 + h + 1)
     o = Oracle(w, h, 0.0, n=1)
