@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Randomised soak of the HIP path against the CPU oracle (run on the GPU box): random pitch, slip, seed, lane count,
+lane offset, auto-reset, single steps (lean / full) and fused rollouts (streams / sampled / mixed policies / single-agent),
+every lane of every step compared.  Usage: tools/soak.py [seconds]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from gym_soccer_littman94_amd import SoccerBatch
+from oracle.oracle import Oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(time.time()))
+pitches = [(5, 4), (6, 4), (7, 5), (9, 6), (11, 7), (5, 5), (8, 4), (6, 6), (13, 9)]
+slips = [0.0, 0.0, 0.2, 0.1, 0.3, 0.5, 0.9, 1.0, 0.05, 1 / 3, 0.25]
+t0 = time.time(); rounds = 0; lanes_steps = 0
+while time.time() - t0 < budget:
+    w, h = pitches[rng.integers(len(pitches))]; slip = slips[rng.integers(len(slips))]
+    n = int(rng.choice([4, 64, 1000, 4096, 4099, 8192 + 4 * int(rng.integers(0, 50))]))
+    off = int(rng.integers(0, 1 << 40)) & ~3 if rng.random() < 0.8 else int(rng.integers(0, 1 << 20))
+    seed = int(rng.integers(0, 1 << 62)); autoreset = bool(rng.random() < 0.7)
+    ms = int(rng.choice([100, 100, 17, 127, 200]))
+    b = SoccerBatch(n, w, h, slip, seed=seed, autoreset=autoreset, lane_offset=off, max_steps=ms, step_stats=bool(rng.random() < 0.5))
+    o = Oracle(w, h, slip, n=n, seed=seed, autoreset=autoreset, lane_offset=off, max_steps=ms)
+    tag = "pitch %dx%d slip %g n %d off %d seed %d autoreset %s max_steps %d" % (w, h, slip, n, off, seed, autoreset, ms)
+    try:
+        b.reset(); cur = o.reset()
+        full = rng.random() < 0.5
+        aa = b.alloc(n, np.int8); ab = b.alloc(n, np.int8)
+        obs = b.alloc(n, np.uint16); rew = b.alloc(n, np.int8); te = b.alloc(n, np.uint8); tr = b.alloc(n, np.uint8)
+        code = b.alloc(n, np.uint8) if full else None; fin = b.alloc(n, np.uint16) if full else None
+        for k in range(int(rng.integers(5, 60))):
+            a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+            aa.upload(a[0]); ab.upload(a[1])
+            b.step(aa, ab, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin)
+            c = o.step(a[0], a[1])
+            assert np.array_equal(obs.download(), c["obs"]) and np.array_equal(rew.download(), c["reward"]), "step " + tag
+            assert np.array_equal(te.download(), c["terminated"]) and np.array_equal(tr.download(), c["truncated"]), "step flags " + tag
+            if full:
+                assert np.array_equal(code.download(), c["prob_code"]) and np.array_equal(fin.download(), c["final_obs"]), "step full " + tag
+            cur = c["obs"]; lanes_steps += n
+        if rng.random() < 0.3:      # masked reset in between
+            m = (rng.random(n) < 0.3).astype(np.uint8)
+            md = b.alloc(n, np.uint8).upload(m)
+            b.reset(mask=md, obs=obs); cur = o.reset(mask=m)
+            assert np.array_equal(obs.download(), cur), "masked reset " + tag
+        T = int(rng.integers(1, 50)); mode = rng.integers(0, 4)
+        O = b.alloc((T, n), np.uint16); R = b.alloc((T, n), np.int8); TE = b.alloc((T, n), np.uint8); TR = b.alloc((T, n), np.uint8)
+        kw = dict(obs=O, reward=R, terminated=TE, truncated=TR, out_stride=n)
+        acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+        mix = None; pol = None
+        if mode == 0:
+            A = b.alloc((T, n), np.int8).upload(acts[:, 0]); B = b.alloc((T, n), np.int8).upload(acts[:, 1])
+            b.rollout(T, A, B, act_stride=n, **kw)
+        elif mode == 1:
+            b.rollout(T, sample_actions=True, **kw)
+        elif mode == 2:
+            mix = [SoccerBatch.mixed_policy_thresholds(rng.dirichlet(np.ones(5) * 0.5, size=o.nS)) for _ in range(2)]
+            da = b.alloc(mix[0].shape, np.uint16).upload(mix[0]); db = b.alloc(mix[1].shape, np.uint16).upload(mix[1])
+            b.rollout(T, sample_actions=True, mix_a=da, mix_b=db, **kw)
+        else:
+            pol = rng.integers(0, 5, size=o.nS).astype(np.int8)
+            b.set_policy("player_b", pol)
+            A = b.alloc((T, n), np.int8).upload(acts[:, 0])
+            b.rollout(T, A, None, act_stride=n, **kw)
+        Oh, Rh, TEh, TRh = O.download(), R.download(), TE.download(), TR.download()
+        for k in range(T):
+            if mode == 0: a, bb = acts[k, 0], acts[k, 1]
+            elif mode == 1: a, bb = o.sample_actions_mixed(cur)
+            elif mode == 2: a, bb = o.sample_actions_mixed(cur, mix[0], mix[1])
+            else: a, bb = acts[k, 0], pol[cur]
+            c = o.step(a, bb)
+            assert np.array_equal(Oh[k], c["obs"]) and np.array_equal(Rh[k], c["reward"]), "rollout mode %d step %d %s" % (mode, k, tag)
+            assert np.array_equal(TEh[k], c["terminated"]) and np.array_equal(TRh[k], c["truncated"]), "rollout flags " + tag
+            cur = c["obs"]; lanes_steps += n
+        s = b.get_state()
+        for key, v in (("row_a", o.row_a), ("col_a", o.col_a), ("row_b", o.row_b), ("col_b", o.col_b), ("poss", o.poss & 1), ("needs_reset", (o.poss >> 1) & 1), ("t", o.t)):
+            assert np.array_equal(s[key], v), "state %s %s" % (key, tag)
+        assert b.tick == o.tick, "tick " + tag
+    finally:
+        b.close()
+    rounds += 1
+print("soak ok: %d random configurations, %.3g lane-steps compared bit for bit in %.0f s" % (rounds, lanes_steps, time.time() - t0))
