@@ -334,8 +334,9 @@ def main():
                     "return_hist_minus1_0_plus1_over_3_rollouts": [int(x) for x in hsum]}
 
     # ---- optional: the gym-style surface north_star names, VectorSoccerEnv(io="device").step() -------------------------
-    # one Python call per step = one ctypes call = one launch of the FULL kernel (final_obs + prob_code + episode
-    # histogram on top of the four result streams: 22 B per env-step); eager launches, wall clock around K steps
+    # one Python call per step = one ctypes call = one launch of the FULL kernel (final_obs + prob_code + the float32
+    # rewards of both agents + terminated|truncated + episode histogram on top of the four result streams: 31 B per
+    # env-step); eager launches, wall clock around K steps
     vec_env = None
     if not args.no_vector_env and world == 1:
         from gym_soccer_littman94_amd import VectorSoccerEnv
@@ -357,7 +358,9 @@ def main():
             assert v.batch.misuse() == 0
             vec_env = {"api": "VectorSoccerEnv(io='device').step(dict of int8 CUDA tensors)", "steps": KV,
                        "us_per_step": dv / KV * 1e6, "env_steps_per_s": N * KV / dv,
-                       "bytes_per_env_step": 22, "note": "rewards as float32 / info['p'] / _final_observation are computed on access"}
+                       "bytes_per_env_step": 31,
+                       "note": "float32 rewards of both agents and infos['_final_observation'] are written by the step kernel; "
+                               "info[agent]['p'] is computed on access"}
             v.close()
 
     if rank == 0:
@@ -394,7 +397,7 @@ def main():
                          "bound_note": "bytes counted at the L2<->fabric boundary (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits "
                                        "are included, and the ~%d MB working set of a run fits the 256 MB Infinity Cache when K is small"
                                        % ((12 * N + 7 * N * K) >> 20),
-                         "kernel": "soccer::step_kernel_swar<false, %s, false>" % ("true" if args.slip else "false"),
+                         "kernel": "soccer::step_kernel_swar<false, %s, false, 1>" % ("1|2" if args.slip else "0"),   # as rocprofv3 prints it
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
             "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
                          "gathered_last_returns": int(gathered.numel()), "gather_allreduce_ms": gather_ms,

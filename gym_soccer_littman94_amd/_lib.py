@@ -31,7 +31,8 @@ class StepArgs(C.Structure):
     _fields_ = [("act_a", C.c_void_p), ("act_b", C.c_void_p), ("u_step", C.c_void_p),
                 ("u_reset", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p),
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("prob_code", C.c_void_p),
-                ("final_obs", C.c_void_p), ("last_return", C.c_void_p)]
+                ("final_obs", C.c_void_p), ("last_return", C.c_void_p),
+                ("reward_a_f32", C.c_void_p), ("reward_b_f32", C.c_void_p), ("finished", C.c_void_p)]
 
 
 class RolloutArgs(C.Structure):

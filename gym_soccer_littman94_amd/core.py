@@ -255,9 +255,11 @@ class SoccerBatch:
         self._check(self.lib.batched_reset(self.h, _ptr(mask), _ptr(u_reset), _ptr(obs)))
 
     def step(self, act_a, act_b, obs=None, reward=None, terminated=None, truncated=None,
-             prob_code=None, u_step=None, u_reset=None, final_obs=None, last_return=None):
+             prob_code=None, u_step=None, u_reset=None, final_obs=None, last_return=None,
+             reward_a_f32=None, reward_b_f32=None, finished=None):
         a = StepArgs(_ptr(act_a), _ptr(act_b), _ptr(u_step), _ptr(u_reset), _ptr(obs), _ptr(reward),
-                     _ptr(terminated), _ptr(truncated), _ptr(prob_code), _ptr(final_obs), _ptr(last_return))
+                     _ptr(terminated), _ptr(truncated), _ptr(prob_code), _ptr(final_obs), _ptr(last_return),
+                     _ptr(reward_a_f32), _ptr(reward_b_f32), _ptr(finished))
         self._check(self.lib.batched_step_ex(self.h, C.byref(a)))
 
     def step_plain(self, act_a, act_b, obs, reward, terminated, truncated, prob_code=None):

@@ -395,10 +395,11 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
         // the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
         const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
         const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
-        const bool full = io.prob_code || io.final_obs || P.step_stats;
+        const bool full = io.prob_code || io.final_obs || io.reward_a_f32 || io.reward_b_f32 || io.finished || P.step_stats;
         SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr,
                      h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_params, P.policy_a, P.policy_b,
-                     io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs};
+                     io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs,
+                     io.reward_a_f32, io.reward_b_f32, io.finished};
 #define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
 #define SWAR_GO(FV, SV, PV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV, 1>), gh, b, 0, h->stream, SWAR_ARGS); \
                                  else hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV, 0>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
@@ -413,7 +414,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
     } else if (vec && shared) {
         // the hot instantiations of the per-lane kernel (slip handles, pitches beyond the byte arithmetic);
         // LEAN drops the code for prob_code / final_obs / last_return / step stats
-        const bool lean = !io.prob_code && !io.final_obs && !io.last_return && !P.step_stats;
+        const bool lean = !io.prob_code && !io.final_obs && !io.last_return && !io.reward_a_f32 && !io.reward_b_f32 && !io.finished && !P.step_stats;
         const int grid = grid_for(h, (P.n + 3) / 4);
         const dim3 g(grid), b(kBlock);
         if (lean) {                 // one 4-lane group per thread, as many workgroups as it takes
@@ -434,18 +435,20 @@ extern "C" int batched_step_ex(soccer_handle* h, const soccer_step_args* a) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (!a || (!a->act_a && !h->P.policy_a) || (!a->act_b && !h->P.policy_b))
         return fail(h, SOCCER_E_INVALID, "batched_step: an action stream is required for every player without a fixed policy");
-    if (!aligned(a->u_step, 8) || !aligned(a->u_reset, 8) || !aligned(a->obs, 2) || !aligned(a->final_obs, 2))
-        return fail(h, SOCCER_E_INVALID, "batched_step: u_* must be 8-byte and obs/final_obs 2-byte aligned");
+    if (!aligned(a->u_step, 8) || !aligned(a->u_reset, 8) || !aligned(a->obs, 2) || !aligned(a->final_obs, 2) ||
+        !aligned(a->reward_a_f32, 4) || !aligned(a->reward_b_f32, 4))
+        return fail(h, SOCCER_E_INVALID, "batched_step: u_* must be 8-byte, reward_*_f32 4-byte and obs/final_obs 2-byte aligned");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // dword I/O needs every byte stream 4-aligned and the uint16 streams 8-aligned; else byte I/O
     const bool vec = h->E != 1 && aligned(a->act_a, 4) && aligned(a->act_b, 4) && aligned(a->reward, 4) &&
                      aligned(a->terminated, 4) && aligned(a->truncated, 4) && aligned(a->prob_code, 4) &&
-                     aligned(a->obs, 8) && aligned(a->final_obs, 8);
+                     aligned(a->obs, 8) && aligned(a->final_obs, 8) && aligned(a->reward_a_f32, 16) && aligned(a->reward_b_f32, 16) &&
+                     aligned(a->finished, 4);
     const bool explicit_u = a->u_step || a->u_reset || h->P.policy_a || h->P.policy_b;   // generic kernel
     KernelParams P = h->P;
     bind_tick(h, P, 1);
     StepIO io{a->act_a, a->act_b, a->u_step, a->u_reset, a->obs, a->reward, a->terminated, a->truncated,
-              a->prob_code, a->final_obs, a->last_return};
+              a->prob_code, a->final_obs, a->last_return, a->reward_a_f32, a->reward_b_f32, a->finished};
     const unsigned long long n = h->P.n, n4 = vec ? (n & ~3ull) : 0ull;
     if (n4) { P.first = 0; P.n = n4; launch_step(h, P, io, explicit_u, true); }
     if (n4 < n) {               // ragged tail (or everything, when the buffers are not dword-aligned)
@@ -831,7 +834,8 @@ extern "C" int soccer_reset_scalar(soccer_handle* h, soccer_scalar_io* io) { ret
 extern "C" int batched_step_host(soccer_handle* h, const soccer_step_args* a) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (!a) return fail(h, SOCCER_E_INVALID, "batched_step: arguments are NULL");
-    if (a->last_return) return fail(h, SOCCER_E_INVALID, "batched_step_host: last_return is device-only");
+    if (a->last_return || a->reward_a_f32 || a->reward_b_f32 || a->finished)
+        return fail(h, SOCCER_E_INVALID, "batched_step_host: last_return / reward_*_f32 / finished are device-only");
     soccer_staging_view v{};
     if (int rc = soccer_staging(h, &v)) return rc;
     const size_t n = h->P.n;

@@ -87,6 +87,7 @@ struct StepIO {
     const double* u_step; const double* u_reset;
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs; int8_t* last_return;
+    float* reward_a_f32; float* reward_b_f32; uint8_t* finished;      // the gym surface's float rewards / terminated | truncated
 };
 
 struct ResetIO {
@@ -786,6 +787,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
             for (int j = 0; j < cnt; ++j)
                 if ((fin_mask >> j) & 1u) IO.last_return[i0 + j] = (int8_t)(o_rew >> (8 * j));
         }
+        if (!LEAN && (IO.reward_a_f32 || IO.reward_b_f32 || IO.finished)) {
+            for (int j = 0; j < cnt; ++j) {
+                const float f = (float)(int8_t)(o_rew >> (8 * j));
+                if (IO.reward_a_f32) IO.reward_a_f32[i0 + j] = f;
+                if (IO.reward_b_f32) IO.reward_b_f32[i0 + j] = 0.0f - f;
+                if (IO.finished) IO.finished[i0 + j] = (uint8_t)(((o_term | o_trunc) >> (8 * j)) & 1u);
+            }
+        }
     }
     if (mis) P.misuse[0] = 1u;
     if (bad_act) P.misuse[1] = 1u;
@@ -984,6 +993,7 @@ struct SwarParams {
     const int8_t* policy_a; const int8_t* policy_b;   // POLICY: the fixed side's int8[nS] policy (the other is nullptr)
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs;
+    float* reward_a_f32; float* reward_b_f32; uint8_t* finished;      // FULL only
 };
 
 // FULL: also final_obs / prob_code (VectorSoccerEnv's info) and, when Q.hist is set, the episode histogram.
@@ -1063,6 +1073,15 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
             if (Q.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(Q.prob_code + i0));
             if (Q.final_obs) __builtin_nontemporal_store((unsigned long long)o.fin_lo | ((unsigned long long)o.fin_hi << 32),
                                                          reinterpret_cast<unsigned long long*>(Q.final_obs + i0));
+            if (Q.reward_a_f32 || Q.reward_b_f32) {                 // the rewards as the floats a gym caller reads (:400-402)
+                const int32_t r = (int32_t)o.rew;
+                const float f0 = (float)((r << 24) >> 24), f1 = (float)((r << 16) >> 24), f2 = (float)((r << 8) >> 24), f3 = (float)(r >> 24);
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                if (Q.reward_a_f32) { const f4 va = {f0, f1, f2, f3}; __builtin_nontemporal_store(va, reinterpret_cast<f4*>(Q.reward_a_f32 + i0)); }
+                if (Q.reward_b_f32) { const f4 vb = {0.0f - f0, 0.0f - f1, 0.0f - f2, 0.0f - f3};
+                                      __builtin_nontemporal_store(vb, reinterpret_cast<f4*>(Q.reward_b_f32 + i0)); }
+            }
+            if (Q.finished) __builtin_nontemporal_store(o.term | o.trunc, reinterpret_cast<uint32_t*>(Q.finished + i0));
             // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends the episode
             if (stats) hist.add_totals((uint32_t)__builtin_popcount(o.finished & swar::K80),
                                        (int32_t)__builtin_popcount(o.rew & swar::K01) - 2 * (int32_t)__builtin_popcount(o.rew & swar::K80),

@@ -14,7 +14,10 @@ Two I/O modes:
     staging block when `copy=False` (one copy in, one kernel, one copy out over PCIe per step; valid
     until the next step()), private copies with the default `copy=True` (gym.vector's convention);
   * device: actions are torch CUDA int8 tensors; results are torch tensors living in buffers the env
-    owns, nothing is synchronised — the mode for rollout loops that stay on the GPU.
+    owns, nothing is synchronised — the mode for rollout loops that stay on the GPU.  The float32 rewards of the
+    returned agents and `infos["_final_observation"]` are written by the step kernel itself (`float_rewards=True`, the
+    default: +4 B per env-step and agent instead of a 5 us cast kernel per read); `float_rewards=False` leaves them to
+    be computed on first access and `reward_int8` is then the zero-cost way to read player A's reward.
 Per-lane randomness is Philox4x32-10 keyed by (seed, global lane id, tick): include/soccer_hip.h.
 """
 import numpy as np
@@ -27,13 +30,14 @@ AGENTS = ('player_a', 'player_b')
 
 class _Lazy(dict):
     """A dict whose values are computed on first access (and cached until `invalidate()`): device mode returns one
-    of these for everything that would cost an extra kernel launch per step — `info[agent]["p"]` (a gather + a
+    of these for everything that would cost an extra kernel launch per step and that the step kernel does not write itself — `info[agent]["p"]` (a gather + a
     cast), the float32 rewards (a cast; a negation for player_b) and `infos["_final_observation"]` (an OR) — so a
     rollout loop that does not look at them pays one launch per step and nothing else."""
-    def __init__(self, thunks, eager=None):
+    def __init__(self, thunks, eager=None, dirty=None):
         super().__init__(eager or {})
         self._thunks = thunks
         self._eager = dict(eager or {})
+        self._dirty = dirty            # the owner's list of dicts holding a computed value (what the next step must drop)
 
     def invalidate(self):
         dict.clear(self)
@@ -44,6 +48,8 @@ class _Lazy(dict):
             raise KeyError(key)
         v = self._thunks[key]()
         self[key] = v
+        if self._dirty is not None:
+            self._dirty.append(self)
         return v
 
     def get(self, key, default=None):
@@ -70,8 +76,8 @@ class _Lazy(dict):
 
 class _LazyInfo(_Lazy):
     """info[agent]: 'p' computed on first access."""
-    def __init__(self, make_p):
-        super().__init__({"p": make_p})
+    def __init__(self, make_p, dirty=None):
+        super().__init__({"p": make_p}, dirty=dirty)
 
 
 class VectorSoccerEnv:
@@ -79,13 +85,14 @@ class VectorSoccerEnv:
 
     def __init__(self, num_envs, width=5, height=4, slip_prob=0.0, seed=0, autoreset=True,
                  device=0, lane_offset=0, max_episode_steps=100, io="numpy", strict=True,
-                 envs_per_thread=0, player_a_policy=None, player_b_policy=None, copy=True):
+                 envs_per_thread=0, player_a_policy=None, player_b_policy=None, copy=True, float_rewards=True):
         assert io in ("numpy", "device"), "io must be 'numpy' or 'device'"
         assert not (player_a_policy is not None and player_b_policy is not None), \
             "Both players cannot have a policy. At least one must be None."
         self.num_envs = int(num_envs)
         self.io = io
         self.strict = strict
+        self.float_rewards = bool(float_rewards)
         self.copy = bool(copy)      # numpy io: return copies (gym.vector's default) or views over the staging block
         stream = None
         if io == "device":
@@ -134,18 +141,31 @@ class VectorSoccerEnv:
             self._ret_obs = {ag: self._obs for ag in ags}
             self._ret_term = {ag: term_b for ag in ags}
             self._ret_trunc = {ag: trunc_b for ag in ags}
-            rew_thunks = {}
-            if 'player_a' in ags: rew_thunks['player_a'] = lambda: self._rew.to(t.float32)
-            if 'player_b' in ags: rew_thunks['player_b'] = lambda: -self._rew.to(t.float32)      # :400-402, :243-244
-            self._ret_rew = _Lazy(rew_thunks)
-            self._ret_p = _LazyInfo(lambda: self._prob[self._code.long()])       # np.round(prob, 2) of the sampled transition (:405)
+            self._stale = []            # lazy dicts that computed something since the last step
+            f32 = {}
+            if self.float_rewards:      # the kernel writes the floats (and terminated | truncated) next to the int8 stream
+                f32 = {ag: t.zeros(n, dtype=t.float32, device=d) for ag in ags}
+                self._finished = t.zeros(n, dtype=t.uint8, device=d)
+                self._ret_rew = dict(f32)
+            else:
+                rew_thunks = {}
+                if 'player_a' in ags: rew_thunks['player_a'] = lambda: self._rew.to(t.float32)
+                if 'player_b' in ags: rew_thunks['player_b'] = lambda: 0.0 - self._rew.to(t.float32)      # :400-402, :243-244
+                self._ret_rew = _Lazy(rew_thunks, dirty=self._stale)
+            self._ret_p = _LazyInfo(lambda: self._prob[self._code.long()], dirty=self._stale)       # np.round(prob, 2) of the sampled transition (:405)
             eager = {ag: self._ret_p for ag in ags}
             eager["final_observation"] = {ag: self._fin for ag in ags}
-            self._ret_infos = _Lazy({"_final_observation": lambda: term_b | trunc_b}, eager)
+            if self.float_rewards:
+                eager["_final_observation"] = self._finished.view(t.bool)
+                self._ret_infos = eager
+            else:
+                self._ret_infos = _Lazy({"_final_observation": lambda: term_b | trunc_b}, eager, dirty=self._stale)
             from .._lib import StepArgs
+            fptr = lambda ag: f32[ag].data_ptr() if ag in f32 else None
             self._step_args = StepArgs(None, None, None, None, self._obs.data_ptr(), self._rew.data_ptr(),
                                        self._term.data_ptr(), self._trunc.data_ptr(), self._code.data_ptr(),
-                                       self._fin.data_ptr(), None)
+                                       self._fin.data_ptr(), None, fptr('player_a'), fptr('player_b'),
+                                       self._finished.data_ptr() if self.float_rewards else None)
             self._step_call = b.lib.batched_step_ex
             import ctypes
             self._step_ref = ctypes.byref(self._step_args)
@@ -235,7 +255,10 @@ class VectorSoccerEnv:
         args.act_a = a.data_ptr() if a is not None else None
         args.act_b = bb.data_ptr() if bb is not None else None
         b._check(self._step_call(b.h, self._step_ref))
-        self._ret_rew.invalidate(); self._ret_p.invalidate(); self._ret_infos.invalidate()
+        if self._stale:                                  # only what the caller actually looked at is dropped
+            for lz in self._stale:
+                lz.invalidate()
+            del self._stale[:]
         return self._ret_obs, self._ret_rew, self._ret_term, self._ret_trunc, self._ret_infos
 
     @property

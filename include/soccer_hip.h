@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SOCCER_ABI_VERSION 1
+#define SOCCER_ABI_VERSION 2      /* 2: soccer_step_args grew reward_a_f32 / reward_b_f32 / finished */
 
 /* error codes */
 #define SOCCER_OK            0
@@ -117,6 +117,11 @@ typedef struct soccer_step_args {
     uint16_t*      final_obs;   /* [n] observation BEFORE auto-reset (equals obs when none fired) */
     int8_t*        last_return; /* [n] A's return of the lane's most recently finished episode; written
                                    only on the step an episode ends (terminated or truncated) */
+    /* ABI 2: what a gym-style caller reads every step, written by the same launch instead of by cast kernels of its own
+     * (device pointers only; NULL = skipped) */
+    float*         reward_a_f32; /* [n] player A's reward as float32 (-1.0 / 0.0 / +1.0), :400 */
+    float*         reward_b_f32; /* [n] player B's reward as float32 = 0 - A's (:401-402); zeros are +0.0 */
+    uint8_t*       finished;     /* [n] terminated | truncated (the vector env's infos["_final_observation"]) */
 } soccer_step_args;
 
 /* batched_rollout arguments: T fused steps with state held in registers.

@@ -29,16 +29,31 @@ class _IO:
         self.term = b.alloc(n, np.uint8); self.trunc = b.alloc(n, np.uint8)
         self.code = b.alloc(n, np.uint8) if full else None
         self.fin = b.alloc(n, np.uint16) if full else None
+        # the gym surface's outputs (ABI 2): float32 rewards of both players and terminated | truncated, from the same launch
+        self.rfa = b.alloc(n, np.float32).fill(7) if full else None
+        self.rfb = b.alloc(n, np.float32).fill(7) if full else None
+        self.done = b.alloc(n, np.uint8).fill(7) if full else None
 
     def step(self, a, bb):
         if a is not None: self.aa.upload(a)
         if bb is not None: self.ab.upload(bb)
         self.b.step(self.aa if a is not None else None, self.ab if bb is not None else None, obs=self.obs, reward=self.rew,
-                    terminated=self.term, truncated=self.trunc, prob_code=self.code, final_obs=self.fin)
+                    terminated=self.term, truncated=self.trunc, prob_code=self.code, final_obs=self.fin,
+                    reward_a_f32=self.rfa, reward_b_f32=self.rfb, finished=self.done)
         out = dict(obs=self.obs.download(), reward=self.rew.download(), terminated=self.term.download(), truncated=self.trunc.download())
         if self.full:
             out.update(prob_code=self.code.download(), final_obs=self.fin.download())
+            _check_gym_outputs(out, self.rfa.download(), self.rfb.download(), self.done.download())
         return out
+
+
+def _check_gym_outputs(out, rfa, rfb, done):
+    """reward_a_f32 / reward_b_f32 / finished are the int8 reward and the two flags in the types a gym caller reads
+    (:400-404): exactly +-1.0 / 0.0, B = 0 - A with positive zeros, finished = terminated | truncated"""
+    r = out["reward"].astype(np.float32)
+    np.testing.assert_array_equal(rfa.view(np.uint32), r.view(np.uint32))
+    np.testing.assert_array_equal(rfb.view(np.uint32), (np.float32(0) - r).view(np.uint32))
+    np.testing.assert_array_equal(done, out["terminated"] | out["truncated"])
 
 
 def _check(got, exp, k):
@@ -278,6 +293,81 @@ def test_handles_beyond_the_byte_arithmetic_take_the_per_lane_kernels(w, h, slip
         cur = c["obs"]
     _state_equal(b, o)
     b.close()
+
+
+@pytest.mark.parametrize("w,h,slip,n,shift", [(13, 9, 0.0, 4096, 0), (13, 9, 0.2, 4096, 0), (5, 4, 0.0, 4099, 0), (5, 4, 0.2, 4098, 0),
+                                              (5, 4, 0.0, 4096, 1), (5, 4, 0.2, 4101, 3), (5, 4, 0.33, 4096, 0)])
+def test_gym_outputs_on_the_per_lane_and_unaligned_paths(w, h, slip, n, shift):
+    """reward_a_f32 / reward_b_f32 / finished from the kernels next to the byte-parallel one: pitches beyond the byte
+    arithmetic, slip values without an exact integer decision (0.33), ragged lane counts (a byte-I/O tail launch) and float
+    streams that are only 4-byte aligned (the whole step falls back to byte I/O)"""
+    rng = np.random.default_rng(n + shift)
+    b = SoccerBatch(n, w, h, slip, seed=9, autoreset=True, step_stats=True)
+    o = Oracle(w, h, slip, n=n, seed=9, autoreset=True)
+    aa = b.alloc(n, np.int8); ab = b.alloc(n, np.int8)
+    rew = b.alloc(n, np.int8); term = b.alloc(n, np.uint8); trunc = b.alloc(n, np.uint8); obs = b.alloc(n, np.uint16)
+    rfa = b.alloc(n + 4, np.float32).fill(7); rfb = b.alloc(n + 4, np.float32).fill(7); done = b.alloc(n + 4, np.uint8).fill(7)
+    b.reset(); o.reset()
+    for k in range(130):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        aa.upload(a[0]); ab.upload(a[1])
+        b.step(aa, ab, obs=obs, reward=rew, terminated=term, truncated=trunc,
+               reward_a_f32=rfa.ptr + 4 * shift, reward_b_f32=rfb.ptr + 4 * shift, finished=done.ptr + shift)
+        exp = o.step(a[0], a[1])
+        out = dict(obs=obs.download(), reward=rew.download(), terminated=term.download(), truncated=trunc.download())
+        _check(out, {key: exp[key] for key in out}, k)
+        _check_gym_outputs(out, rfa.download()[shift:shift + n], rfb.download()[shift:shift + n], done.download()[shift:shift + n])
+    # nothing was written outside [shift, shift + n)
+    for arr, fill in ((rfa.download().view(np.uint32), 0x07070707), (rfb.download().view(np.uint32), 0x07070707), (done.download(), 7)):
+        assert (arr[:shift] == fill).all() and (arr[shift + n:] == fill).all()
+    _state_equal(b, o)
+    np.testing.assert_array_equal(b.stats()[0], o.hist)
+    b.close()
+
+
+def test_gym_outputs_are_device_only():
+    n = 64
+    b = SoccerBatch(n, 5, 4, 0.0, seed=1)
+    b.reset()
+    a = np.zeros(n, np.int8); f = np.zeros(n, np.float32)
+    from gym_soccer_littman94_amd._lib import StepArgs
+    args = StepArgs(a.ctypes.data, a.ctypes.data, None, None, None, None, None, None, None, None, None, f.ctypes.data, None, None)
+    import ctypes
+    assert b.lib.batched_step_host(b.h, ctypes.byref(args)) != 0
+    assert "device-only" in b.lib.soccer_last_error(b.h).decode()
+    b.close()
+
+
+@pytest.mark.parametrize("slip", [0.0, 0.2])
+@pytest.mark.parametrize("fixed", [None, "player_a", "player_b"])
+def test_vector_env_float_rewards_by_the_kernel_equal_the_lazy_casts(slip, fixed):
+    """VectorSoccerEnv(io="device"): float_rewards=True (the step kernel writes the float32 rewards and
+    infos["_final_observation"]) returns what float_rewards=False computes on access, for both agents and in single-agent mode"""
+    import torch
+    n = 4096
+    rng = np.random.default_rng(5)
+    kw = dict(slip_prob=slip, seed=3, io="device")
+    nS = VectorSoccerEnv(4, slip_prob=slip).nS
+    if fixed:
+        kw[fixed + "_policy"] = rng.integers(0, 5, size=nS).astype(np.int8)
+    v1 = VectorSoccerEnv(n, float_rewards=True, **kw); v2 = VectorSoccerEnv(n, float_rewards=False, **kw)
+    o1 = v1.reset(); o2 = v2.reset()
+    ags = v1.return_agent
+    assert ags == v2.return_agent
+    for k in range(120):
+        act = {ag: torch.from_numpy(rng.integers(0, 5, size=n, dtype=np.int8)).cuda() for ag in ags}
+        ob1, r1, te1, tr1, i1 = v1.step(act)
+        ob2, r2, te2, tr2, i2 = v2.step(act)
+        for ag in ags:
+            assert r1[ag].dtype == torch.float32 and r1[ag].shape == (n,)
+            assert torch.equal(r1[ag], r2[ag]) and torch.equal(ob1[ag], ob2[ag])
+            assert torch.equal(r1[ag], (v1.reward_int8.float() if ag == "player_a" else 0.0 - v1.reward_int8.float()))
+            assert torch.equal(te1[ag], te2[ag]) and torch.equal(tr1[ag], tr2[ag])
+            assert torch.equal(i1[ag]["p"], i2[ag]["p"])
+        assert i1["_final_observation"].dtype == torch.bool
+        assert torch.equal(i1["_final_observation"], i2["_final_observation"])
+        assert torch.equal(i1["_final_observation"], te1[ags[0]] | tr1[ags[0]])
+    v1.close(); v2.close()
 
 
 def test_bad_actions_on_host_paths_are_refused_before_any_launch():

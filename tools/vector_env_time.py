@@ -22,9 +22,22 @@ for n in sizes:
     v = VectorSoccerEnv(n, seed=0, io="device")
     v.reset()
     ta = torch.from_numpy(a).cuda()
-    for k in range(3): v.step({'player_a': ta[k, 0], 'player_b': ta[k, 1]})
-    torch.cuda.synchronize(); t = time.perf_counter(); K = 300
-    for k in range(K): v.step({'player_a': ta[k % 8, 0], 'player_b': ta[k % 8, 1]})
+    K = 2000
+    pairs = [{'player_a': ta[k % 8, 0], 'player_b': ta[k % 8, 1]} for k in range(K)]      # slicing is not the env's cost
+    for k in range(50): v.step(pairs[k])
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for k in range(K): v.step(pairs[k])
     torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print("device io  n=%8d: %8.1f us/step  %.3g env-steps/s (incl. the wrapper's torch ops for rewards/flags/info)" % (n, dt / K * 1e6, n * K / dt))
+    print("device io  n=%8d: %8.2f us/step  %.3g env-steps/s (rewards as float32 / info['p'] left lazy)" % (n, dt / K * 1e6, n * K / dt))
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for k in range(K):
+        o, r, te, tr, info = v.step(pairs[k]); r["player_a"]
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("device io  n=%8d: %8.2f us/step  (reading the float32 reward of player_a every step: + one cast kernel)" % (n, dt / K * 1e6))
+    # the floor under step(): the bare ctypes call it makes
+    call, h, ref = v._step_call, v.batch.h, v._step_ref
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for k in range(K): call(h, ref)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("           n=%8d: %8.2f us per bare batched_step_ex ctypes call (same launch, no Python around it)" % (n, dt / K * 1e6))
     v.close()
