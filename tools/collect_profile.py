@@ -50,7 +50,7 @@ def _csrc_sha():
         if f.endswith(('.hip', '.hpp', 'Makefile')):
             h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()
-t.update(build=tag, csrc_sha256=_csrc_sha(), commit=subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip(),
+t.update(round=int(tag[1:3]) if tag[:1] == 'r' and tag[1:3].isdigit() else t.get('round'), build=tag, csrc_sha256=_csrc_sha(), commit=subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip(),
          algorithmic_bytes_per_launch=19 * (1 << 20))
 t.update(kernel=k, FETCH_SIZE_KB_mean=means[(k, 'FETCH_SIZE')], WRITE_SIZE_KB_mean=means[(k, 'WRITE_SIZE')],
          step_kernel_hbm_bytes_per_launch=(2 * means[(k, 'FETCH_SIZE')] + means[(k, 'WRITE_SIZE')]) * 1024)
