@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the HIP path against the CPU oracle (run on the GPU box): random pitch, slip, seed, lane count,
 lane offset, auto-reset, single steps (lean / full) and fused rollouts (streams / sampled / mixed policies / single-agent),
-every lane of every step compared.  Usage: tools/soak.py [seconds]"""
+every lane of every step compared (incl. the ABI-2 gym outputs, aligned and not).  Usage: tools/soak.py [seconds [seed]]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -9,7 +9,9 @@ from gym_soccer_littman94_amd import SoccerBatch
 from oracle.oracle import Oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(time.time()))
+soak_seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())       # printed, so a failing run can be repeated exactly
+print("soak seed %d" % soak_seed, flush=True)
+rng = np.random.default_rng(soak_seed)
 pitches = [(5, 4), (6, 4), (7, 5), (9, 6), (11, 7), (5, 5), (8, 4), (6, 6), (13, 9)]
 slips = [0.0, 0.0, 0.2, 0.1, 0.3, 0.5, 0.9, 1.0, 0.05, 1 / 3, 0.25]
 t0 = time.time(); rounds = 0; lanes_steps = 0
@@ -28,16 +30,35 @@ while time.time() - t0 < budget:
         aa = b.alloc(n, np.int8); ab = b.alloc(n, np.int8)
         obs = b.alloc(n, np.uint16); rew = b.alloc(n, np.int8); te = b.alloc(n, np.uint8); tr = b.alloc(n, np.uint8)
         code = b.alloc(n, np.uint8) if full else None; fin = b.alloc(n, np.uint16) if full else None
+        # the gym outputs (ABI 2), each asked for independently and sometimes only 4-byte aligned (byte-I/O fallback)
+        gym = full and rng.random() < 0.6
+        sh = int(rng.choice([0, 0, 0, 1, 3])) if gym else 0
+        rfa = b.alloc(n + 4, np.float32).fill(7) if gym and rng.random() < 0.8 else None
+        rfb = b.alloc(n + 4, np.float32).fill(7) if gym and rng.random() < 0.8 else None
+        dn = b.alloc(n + 4, np.uint8).fill(7) if gym and rng.random() < 0.8 else None
         for k in range(int(rng.integers(5, 60))):
             a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
             aa.upload(a[0]); ab.upload(a[1])
-            b.step(aa, ab, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin)
+            b.step(aa, ab, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin,
+                   reward_a_f32=None if rfa is None else rfa.ptr + 4 * sh, reward_b_f32=None if rfb is None else rfb.ptr + 4 * sh,
+                   finished=None if dn is None else dn.ptr + sh)
             c = o.step(a[0], a[1])
             assert np.array_equal(obs.download(), c["obs"]) and np.array_equal(rew.download(), c["reward"]), "step " + tag
             assert np.array_equal(te.download(), c["terminated"]) and np.array_equal(tr.download(), c["truncated"]), "step flags " + tag
             if full:
                 assert np.array_equal(code.download(), c["prob_code"]) and np.array_equal(fin.download(), c["final_obs"]), "step full " + tag
+            r32 = c["reward"].astype(np.float32)
+            if rfa is not None:
+                assert np.array_equal(rfa.download()[sh:sh + n].view(np.uint32), r32.view(np.uint32)), "reward_a_f32 " + tag
+            if rfb is not None:
+                assert np.array_equal(rfb.download()[sh:sh + n].view(np.uint32), (np.float32(0) - r32).view(np.uint32)), "reward_b_f32 " + tag
+            if dn is not None:
+                assert np.array_equal(dn.download()[sh:sh + n], c["terminated"] | c["truncated"]), "finished " + tag
             cur = c["obs"]; lanes_steps += n
+        for arr, fill in ((rfa, 0x07070707), (rfb, 0x07070707), (dn, 7)):       # nothing written outside [sh, sh + n)
+            if arr is not None:
+                d = arr.download(); d = d.view(np.uint32) if d.dtype == np.float32 else d
+                assert (d[:sh] == fill).all() and (d[sh + n:] == fill).all(), "gym output overrun " + tag
         if rng.random() < 0.3:      # masked reset in between
             m = (rng.random(n) < 0.3).astype(np.uint8)
             md = b.alloc(n, np.uint8).upload(m)
