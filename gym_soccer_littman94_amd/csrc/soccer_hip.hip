@@ -67,7 +67,7 @@ struct soccer_handle {
     // byte-parallel step (soccer_swar.hpp)
     swar::Consts swar_c{}; bool swar_ok = false;
     swar::SlipConsts slip_c{}; bool slip_swar_ok = false;   // integer slip selection usable by the byte-parallel kernels
-    KernelParams* d_params = nullptr;       // slip_int == 2: device copy of P for the rare float64 walk inside those kernels
+    size_t hist_slots = kHistSlots;         // per-wave histogram slots (a power of two; see soccer_create)
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
@@ -112,7 +112,7 @@ static void free_handle(soccer_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_params};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -212,14 +212,17 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     CREATE_TRY(hipMemcpy(h->d_nc, R.next_cell.data(), R.next_cell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&h->d_tick, 256));
     CREATE_TRY(hipMemset(h->d_tick, 0, 256));
-    CREATE_TRY(hipMalloc(&h->d_hist, sizeof(unsigned long long) * kHistSlots * kHistStride));
-    CREATE_TRY(hipMemset(h->d_hist, 0, sizeof(unsigned long long) * kHistSlots * kHistStride));
+    // one private histogram slot per wave of the largest grid that counts episodes: the capped grids (rollout, per-lane
+    // step) stay below kHistSlots waves; the byte-parallel step launches one wave per 256 lanes, uncapped
+    while (h->hist_slots < (n + 255) / 256) h->hist_slots <<= 1;
+    CREATE_TRY(hipMalloc(&h->d_hist, sizeof(unsigned long long) * h->hist_slots * kHistStride));
+    CREATE_TRY(hipMemset(h->d_hist, 0, sizeof(unsigned long long) * h->hist_slots * kHistStride));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->misuse_host), 128, hipHostMallocMapped));
     std::memset(h->misuse_host, 0, 128);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_misuse), h->misuse_host, 0));
 
     P.next_cell = h->d_nc; P.isd = h->d_isd;
-    P.hist = h->d_hist; P.misuse = h->d_misuse;
+    P.hist = h->d_hist; P.hist_mask = (uint32_t)(h->hist_slots - 1); P.misuse = h->d_misuse;
     P.lane_offset = cfg->lane_offset;
     P.first = 0; P.n = n; P.W = R.W; P.HW = R.H * R.W; P.HW5 = 5 * R.H * R.W;
     P.nc_len = static_cast<int32_t>(R.next_cell.size());
@@ -234,7 +237,6 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
         for (int i = 0; i < 4; ++i) P.w[i] = ST.w[i];
         for (int i = 0; i < 9; ++i) { P.B[i] = ST.B[i]; P.CB[i] = ST.CB[i]; }
         P.nb = ST.nb; P.act_pack = ST.act_pack; P.slip_int = ST.slip_int;
-        for (int q = 0; q < 4; ++q) P.danger[q] = ST.danger[q];
         static_assert(sizeof(swar::Quad) == sizeof(uint4), "threshold rows are 16 bytes");
         CREATE_TRY(hipMalloc(&h->d_sub, sizeof(ST.sub)));
         CREATE_TRY(hipMemcpy(h->d_sub, ST.sub, sizeof(ST.sub), hipMemcpyHostToDevice));
@@ -272,7 +274,8 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
         RAISE(1) RAISE(4) RAISE(8)
 #undef RAISE
         if (se == hipSuccess)
-            se = hipFuncSetAttribute(reinterpret_cast<const void*>(h->lut_lds ? &reset_kernel<true> : &reset_kernel<false>),
+            se = hipFuncSetAttribute(h->slip ? reinterpret_cast<const void*>(h->lut_lds ? &reset_kernel<true, true> : &reset_kernel<false, true>)
+                                             : reinterpret_cast<const void*>(h->lut_lds ? &reset_kernel<true, false> : &reset_kernel<false, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
         CREATE_TRY(se);
     }
@@ -281,10 +284,6 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device) == hipSuccess && khz > 0) h->wall_clock_khz = khz; }
     h->grid_cap = prop.multiProcessorCount * 8;
     h->n_cu = prop.multiProcessorCount;
-    if (h->slip_swar_ok && P.slip_int == 2u) {
-        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_params), sizeof(KernelParams)));
-        CREATE_TRY(hipMemcpy(h->d_params, &h->P, sizeof(KernelParams), hipMemcpyHostToDevice));
-    }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     *out = h;
@@ -365,16 +364,20 @@ extern "C" int batched_reset(soccer_handle* h, const uint8_t* mask, const double
     if (n4) {
         ResetSwar RS{h->swar_c, P.state, P.state_stride, n4, P.lane_offset, P.tick_in, P.tick_out, P.key0, P.key1, mask, obs};
         const dim3 g(static_cast<unsigned>(((n4 >> 2) + kBlock - 1) / kBlock)), b(kBlock);
-        if (mask) hipLaunchKernelGGL(reset_kernel_swar<true>, g, b, 0, h->stream, RS);
-        else hipLaunchKernelGGL(reset_kernel_swar<false>, g, b, 0, h->stream, RS);
+        if (h->slip) { if (mask) hipLaunchKernelGGL((reset_kernel_swar<true, true>), g, b, 0, h->stream, RS);
+                       else hipLaunchKernelGGL((reset_kernel_swar<false, true>), g, b, 0, h->stream, RS); }
+        else { if (mask) hipLaunchKernelGGL((reset_kernel_swar<true, false>), g, b, 0, h->stream, RS);
+               else hipLaunchKernelGGL((reset_kernel_swar<false, false>), g, b, 0, h->stream, RS); }
     }
     if (n4 < P.n) {
         KernelParams Q = P;
         Q.first = n4; Q.n = P.n - n4;
         if (n4) Q.tick_out = nullptr;           // the main launch publishes the tick
         const int grid = grid_for(h, Q.n);
-        if (h->lut_lds) hipLaunchKernelGGL(reset_kernel<true>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io);
-        else hipLaunchKernelGGL(reset_kernel<false>, dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io);
+        if (h->slip) { if (h->lut_lds) hipLaunchKernelGGL((reset_kernel<true, true>), dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io);
+                       else hipLaunchKernelGGL((reset_kernel<false, true>), dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io); }
+        else { if (h->lut_lds) hipLaunchKernelGGL((reset_kernel<true, false>), dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io);
+               else hipLaunchKernelGGL((reset_kernel<false, false>), dim3(grid), dim3(kBlock), h->smem_bytes, h->stream, Q, io); }
     }
     HIP_TRY(h, hipGetLastError());
     return SOCCER_OK;
@@ -390,22 +393,26 @@ static void launch_step3(soccer_handle* h, const KernelParams& P, const StepIO& 
 static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& io, bool explicit_u, bool vec) {
     const bool shared = ((P.lane_offset + P.first) & 3ull) == 0ull;
     const bool policy_only = explicit_u && !io.u_step && !io.u_reset;       // fixed-policy handle, Philox draws
-    const bool swar_fit = vec && shared && h->swar_ok && (!h->slip || h->slip_swar_ok) && !io.last_return;
+    const bool swar_fit = vec && shared && h->swar_ok && (!h->slip || h->slip_swar_ok) && aligned(io.last_return, 4);
     if ((policy_only || !explicit_u) && swar_fit) {
         // the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
         const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
         const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
-        const bool full = io.prob_code || io.final_obs || io.reward_a_f32 || io.reward_b_f32 || io.finished || P.step_stats;
-        SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr,
-                     h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_params, P.policy_a, P.policy_b,
+        // which outputs the launch needs decides the instantiation: 0 the four result streams, 1 + the gym floats /
+        // finished / last_return, 2 + final_obs / prob_code / episode histogram
+        const int out = (io.prob_code || io.final_obs || P.step_stats) ? 2
+                      : (io.reward_a_f32 || io.reward_b_f32 || io.finished || io.last_return) ? 1 : 0;
+        SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr, P.hist_mask,
+                     h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.policy_a, P.policy_b,
                      io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs,
-                     io.reward_a_f32, io.reward_b_f32, io.finished};
+                     io.reward_a_f32, io.reward_b_f32, io.finished, io.last_return};
 #define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
-#define SWAR_GO(FV, SV, PV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV, 1>), gh, b, 0, h->stream, SWAR_ARGS); \
-                                 else hipLaunchKernelGGL((step_kernel_swar<FV, SV, PV, 0>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
-#define SWAR_SLIP(FV, PV) do { if (!h->slip) SWAR_GO(FV, 0, PV); else if (P.slip_int == 2u) SWAR_GO(FV, 2, PV); else SWAR_GO(FV, 1, PV); } while (0)
-        if (policy_only) { if (full) SWAR_SLIP(true, true); else SWAR_SLIP(false, true); }
-        else { if (full) SWAR_SLIP(true, false); else SWAR_SLIP(false, false); }
+#define SWAR_GO(OV, SV, PV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 1>), gh, b, 0, h->stream, SWAR_ARGS); \
+                                 else hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 0>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
+#define SWAR_SLIP(OV, PV) do { if (!h->slip) SWAR_GO(OV, false, PV); else SWAR_GO(OV, true, PV); } while (0)
+#define SWAR_OUT(PV) do { if (out == 2) SWAR_SLIP(2, PV); else if (out == 1) SWAR_SLIP(1, PV); else SWAR_SLIP(0, PV); } while (0)
+        if (policy_only) SWAR_OUT(true); else SWAR_OUT(false);
+#undef SWAR_OUT
 #undef SWAR_SLIP
 #undef SWAR_GO
 #undef SWAR_ARGS
@@ -530,9 +537,14 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
             RolloutSwar RS{P.state, P.state_stride, P.first, P.n, P.lane_offset, P.tick_in, P.tick_out, P.hist, P.misuse,
                            P.policy_a, P.policy_b, P.key0, P.key1,
-                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_params, R0.nS, 0};
+                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.hist_mask, R0.nS, 0};
             size_t smem = 36 * sizeof(uint32_t);
-            if (dyn && (io.mix_a || io.mix_b || P.policy_a || P.policy_b)) {
+            const bool fixed = P.policy_a || P.policy_b;
+            // both sides sampled from mixed-policy tables whose 16-byte rows fit LDS: the shape of config 5
+            const bool both_mix = dyn && !fixed && io.sample_actions && io.mix_a && io.mix_b &&
+                                  smem + (size_t)R0.nS * sizeof(uint4) <= 64 * 1024;
+            if (both_mix) { RS.lds_tables = 1; smem += (size_t)R0.nS * sizeof(uint4); }
+            else if (dyn && (io.mix_a || io.mix_b || fixed)) {
                 const size_t need = smem + 2 * (size_t)R0.nS * sizeof(uint2) + 2 * (((size_t)R0.nS + 15) & ~size_t(15));
                 if (need <= 64 * 1024) { RS.lds_tables = 1; smem = need; }
             }
@@ -543,17 +555,15 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
 #define LAUNCH_G(DV, SV, GV) do { if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV, GV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
                                   hipLaunchKernelGGL((rollout_swar_kernel<DV, SV, GV>), g, bl, smem, h->stream, RS, io); } while (0)
 #define LAUNCH_S(DV, SV) do { if (h->swar_c.small) LAUNCH_G(DV, SV, 1); else LAUNCH_G(DV, SV, 0); } while (0)
-            const int sm = !h->slip ? 0 : (P.slip_int == 2u ? 2 : 1);
             // the action source as a compile-time shape (rollout_swar_group): streams / sampled uniformly / both sides from
-            // mixed-policy tables / anything else
-            const bool fixed = P.policy_a || P.policy_b;
+            // mixed-policy tables / single-agent A or B / anything else
             const int dm = !dyn ? 0 : (!fixed && io.sample_actions && !io.mix_a && !io.mix_b) ? 1
-                                : (!fixed && io.sample_actions && io.mix_a && io.mix_b) ? 2
+                                : both_mix ? 2
                                 : (!io.sample_actions && P.policy_a && !P.policy_b && io.act_b) ? 4
                                 : (!io.sample_actions && P.policy_b && !P.policy_a && io.act_a) ? 5 : 3;
 #define LAUNCH_D(SV) do { if (dm == 0) LAUNCH_S(0, SV); else if (dm == 1) LAUNCH_S(1, SV); else if (dm == 2) LAUNCH_S(2, SV); \
                           else if (dm == 4) LAUNCH_S(4, SV); else if (dm == 5) LAUNCH_S(5, SV); else LAUNCH_S(3, SV); } while (0)
-            if (sm == 0) LAUNCH_D(0); else if (sm == 1) LAUNCH_D(1); else LAUNCH_D(2);
+            if (!h->slip) LAUNCH_D(false); else LAUNCH_D(true);
 #undef LAUNCH_D
 #undef LAUNCH_S
 #undef LAUNCH_G
@@ -1129,10 +1139,10 @@ extern "C" int soccer_get_stats(soccer_handle* h, uint64_t hist[3], uint64_t* mi
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (hist) {
-        std::vector<unsigned long long> shards((size_t)kHistSlots * kHistStride);
+        std::vector<unsigned long long> shards(h->hist_slots * kHistStride);
         HIP_TRY(h, hipMemcpy(shards.data(), h->d_hist, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         hist[0] = hist[1] = hist[2] = 0;
-        for (int s = 0; s < kHistSlots; ++s) for (int b = 0; b < 3; ++b) hist[b] += shards[(size_t)s * kHistStride + b];
+        for (size_t s = 0; s < h->hist_slots; ++s) for (int b = 0; b < 3; ++b) hist[b] += shards[s * kHistStride + b];
     }
     if (misuse) {                                   // the stream is idle: no copy needed
         const volatile unsigned int* m = h->misuse_host;
@@ -1150,7 +1160,7 @@ extern "C" uint32_t soccer_peek_misuse(const soccer_handle* h) {
 extern "C" int soccer_reset_stats(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipMemsetAsync(h->d_hist, 0, sizeof(unsigned long long) * kHistSlots * kHistStride, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_hist, 0, sizeof(unsigned long long) * h->hist_slots * kHistStride, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_misuse, 0, 128, h->stream));
     return SOCCER_OK;
 }

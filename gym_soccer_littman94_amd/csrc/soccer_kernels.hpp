@@ -36,7 +36,8 @@ constexpr int kBlock = 256;
 #ifndef SOCCER_HOT_UNROLL_SLIP
 #define SOCCER_HOT_UNROLL_SLIP 4
 #endif
-constexpr int kHistSlots = 16384;        // >= waves of the largest grid (8 blocks x 4 waves x 512 CUs)
+constexpr int kHistSlots = 16384;        // minimum: >= waves of the largest CAPPED grid (8 blocks x 4 waves x 512 CUs); a handle
+                                         // whose byte-parallel step launches more waves than this (n_lanes > 2^22) gets more slots
 constexpr int kHistStride = 4;           // u64 per slot: return -1, 0, +1, pad
 constexpr int kIsdWords = 16;            // LDS: 4 ISD entries x (A, B, poss|obs<<16, pad)
 
@@ -57,7 +58,8 @@ struct KernelParams {
     uint32_t key0, key1;
     unsigned long long lane_offset;
     // statistics
-    unsigned long long* hist;             // [kHistSlots][4]: one private slot per wave of the grid, bins 0..2
+    unsigned long long* hist;             // [hist_mask + 1][4]: one private slot per wave of the grid, bins 0..2
+    uint32_t hist_mask;                   // slots - 1 (a power of two >= the waves of the largest grid that counts)
     unsigned int* misuse;                 // sticky flag
     // geometry / constants
     unsigned long long first;             // first lane (within the handle) this launch covers
@@ -71,15 +73,12 @@ struct KernelParams {
     // slip fast path: cumulative weight after each ACTIVE (non-zero) combination in reference order
     // (+inf beyond), their count, and their combination ids packed 4 bits each
     double B[9]; uint32_t nb; unsigned long long act_pack;
-    // integer form of the same decision for draws that come from a Philox word (u = m * 2^-30, m < 2^30):
-    // u >= b  <=>  m >= ceil(b * 2^30).  Used only when the host has checked that NO threshold of the handle
-    // (9 combination ends CB, 9 x 4 within-combination thresholds `sub`) lies within 2^-10 of an integer after
-    // scaling, i.e. that no such draw can be within 2^-40 of a threshold: then the nominal decision is the exact one
-    // and the float64 walk is never needed (slip_int = 1).
-    uint32_t CB[9]; uint32_t slip_int;    // 0 float64 only, 1 integer only, 2 integer except for draws m in `danger`
-    uint32_t danger[4];                   // slip_int == 2: the (at most four) integers m < 2^30 that sit within 2^-10 of a
-                                          // scaled threshold; lanes drawing one of them walk the float64 sums (p = 2^-30)
-    const uint4* sub;                     // [9] per active combination: { t1 (2 outcomes), t1, t2, t3 (4 outcomes) }, scaled
+    // integer form of the same decision for draws that come from a Philox word (u = (m + 1/2) * 2^-30, m < 2^30):
+    // running sum t <= u  <=>  m >= ceil(t * 2^30 - 1/2).  Used only when the host has checked, by walking every list
+    // shape, that this integer is the same for every shape at every entry position (soccer_slip.hpp): then it is the
+    // reference's decision for every draw and the float64 walk is never needed (slip_int = 1).
+    uint32_t CB[9]; uint32_t slip_int;    // 0 float64 only, 1 integer only
+    const uint4* sub;                     // [9] per active combination: { t1 (2 outcomes), t1, t2, t3 (4 outcomes) }, as integers
 };
 
 struct StepIO {
@@ -121,7 +120,8 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     return Philox4{{c0, c1, c2, c3}};
 }
 
-// the block shared by global lanes 4q .. 4q+3 at `tick`; purpose 0 = step/reset, 1 = sampled actions
+// the block shared by global lanes 4q .. 4q+3 at `tick`; purpose 0 = step/reset, 1 = sampled actions.
+// Callers pass `tick >> 3` for the step/reset block of a slip_prob == 0 handle (one block serves eight ticks).
 __device__ __forceinline__ Philox4 lane_block(const KernelParams& P, unsigned long long q,
                                               unsigned long long tick, uint32_t purpose) {
 #ifdef SOCCER_LAB_NO_PHILOX     // tools/kernel_lab.hip ablation build only
@@ -135,10 +135,19 @@ __device__ __forceinline__ Philox4 lane_block(const KernelParams& P, unsigned lo
 // probabilities are dyadic: slip_prob == 0) and two independent bits for the ISD draw.
 struct Draw { double u; uint32_t top2; uint32_t reset2; uint32_t m; };   // m = w >> 2 for word draws
 
-// lane word w: u = (w >> 2) * 2^-30, reset bits = w & 3
-__device__ __forceinline__ Draw draw_from_word(uint32_t w) {
-    return Draw{(double)(w >> 2) * 0x1.0p-30, w >> 30, w & 3u, w >> 2};
+// The RNG convention of include/soccer_hip.h, per lane:
+//   SLIP (slip_prob > 0): lane word w of the tick's own block: u = ((w >> 2) + 1/2) * 2^-30, reset bits = w & 3
+//   otherwise: the lane's word of the block of tick >> 3; this tick's nibble is number (tick & 7) ^ 1 from the least
+//   significant end: its two high bits are floor(4u) (u = (that + 1/2) / 4), its two low bits the reset draw
+template <bool SLIP>
+__device__ __forceinline__ Draw draw_from_word(uint32_t w, unsigned long long tick) {
+    if (SLIP) return Draw{((double)(w >> 2) + 0.5) * 0x1.0p-30, w >> 30, w & 3u, w >> 2};
+    const uint32_t nib = (w >> (4u * (((uint32_t)tick & 7u) ^ 1u))) & 15u;
+    return Draw{((double)(nib >> 2) + 0.5) * 0.25, nib >> 2, nib & 3u, 0u};
 }
+// the tick a step/reset block is keyed by
+template <bool SLIP>
+__device__ __forceinline__ unsigned long long block_tick(unsigned long long tick) { return SLIP ? tick : tick >> 3; }
 // A caller-supplied uniform.  Values outside [0,1) (and NaN) make every running sum compare
 // "not greater", which categorical_sample resolves to index 0 — same as u = 0.
 __device__ __forceinline__ double sane_uniform(double u) { return ((u >= 0.0) && (u < 1.0)) ? u : 0.0; }
@@ -285,9 +294,7 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         constexpr uint32_t CL2 = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
         const double w0 = P.w[0], w1 = P.w[1], w2 = P.w[2], w3 = P.w[3];
 #define SOCCER_WEIGHT_OF(cl) (((cl) & 2u) ? (((cl) & 1u) ? w3 : w2) : (((cl) & 1u) ? w1 : w0))
-        bool use_int = INT_ONLY || (WORD && P.slip_int != 0u);           // uniform ...
-        if (!INT_ONLY && WORD && P.slip_int == 2u)                      // ... except for a draw on a dangerous integer
-            use_int = !((d.m == P.danger[0]) | (d.m == P.danger[1]) | (d.m == P.danger[2]) | (d.m == P.danger[3]));
+        const bool use_int = INT_ONLY || (WORD && P.slip_int != 0u);     // wave-uniform
         if (use_int) {
             // Integer decision (see KernelParams::CB): combination = number of scaled cumulative weights <= m,
             // outcome within it = number of its scaled thresholds <= m.  No float64, no fallback — and the
@@ -584,24 +591,23 @@ template <bool EARLY>
 struct HistAcc {
     uint32_t fin, pos, neg;     // this thread's finished episodes: all / return +1 / return -1
     ulonglong2 old01; unsigned long long old2;   // EARLY only: the wave's slot as of kernel entry (lane 0)
-    __device__ __forceinline__ unsigned long long* slot_at(unsigned long long* base) const {
+    __device__ __forceinline__ unsigned long long* slot_at(unsigned long long* base, uint32_t mask) const {
         const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        return base + (size_t)(wave % kHistSlots) * kHistStride;
+        return base + (size_t)(wave & mask) * kHistStride;
     }
-    __device__ __forceinline__ unsigned long long* slot(const KernelParams& P) const { return slot_at(P.hist); }
-    // Every wave of a launch owns one slot and launches are stream-ordered, so plain loads and stores
-    // accumulate without atomics.
-    __device__ __forceinline__ void init_at(unsigned long long* base) {
+    // Every wave of a launch owns one slot — the host sizes the array to the largest grid that counts (soccer_create) —
+    // and launches are stream-ordered, so plain loads and stores accumulate without atomics.
+    __device__ __forceinline__ void init_at(unsigned long long* base, uint32_t mask) {
         fin = 0u; pos = 0u; neg = 0u;
         if (EARLY) {
             old01 = make_ulonglong2(0ull, 0ull); old2 = 0ull;
             if ((threadIdx.x & 63u) == 0u) {
-                const unsigned long long* h = slot_at(base);
+                const unsigned long long* h = slot_at(base, mask);
                 old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2];
             }
         }
     }
-    __device__ __forceinline__ void init(const KernelParams& P) { init_at(P.hist); }
+    __device__ __forceinline__ void init(const KernelParams& P) { init_at(P.hist, P.hist_mask); }
     __device__ __forceinline__ void add(uint32_t finished, int32_t reward) {
         fin += finished; pos += reward > 0 ? 1u : 0u; neg += reward < 0 ? 1u : 0u;
     }
@@ -611,11 +617,11 @@ struct HistAcc {
         fin += finished; pos += (nonzero + (uint32_t)reward_sum) >> 1; neg += (nonzero - (uint32_t)reward_sum) >> 1;
     }
     // Call once at kernel exit, where every lane of the wave is active.
-    __device__ __forceinline__ void flush(const KernelParams& P) { flush_at(P.hist); }
-    __device__ __forceinline__ void flush_at(unsigned long long* base) {
+    __device__ __forceinline__ void flush(const KernelParams& P) { flush_at(P.hist, P.hist_mask); }
+    __device__ __forceinline__ void flush_at(unsigned long long* base, uint32_t mask) {
         const uint32_t tot = wave_sum(fin), p = wave_sum(pos), n = wave_sum(neg);
         if ((threadIdx.x & 63u) == 0u && tot) {
-            unsigned long long* h = slot_at(base);
+            unsigned long long* h = slot_at(base, mask);
             if (!EARLY) { old01 = *reinterpret_cast<const ulonglong2*>(h); old2 = h[2]; }
             *reinterpret_cast<ulonglong2*>(h) = make_ulonglong2(old01.x + n, old01.y + (tot - p - n));
             h[2] = old2 + p;
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
         // randomness does not depend on the loads above: it is computed while they are in flight
         const bool need_philox = !EXPLICIT_U || (IO.u_step == nullptr) || (P.autoreset && IO.u_reset == nullptr);
         Philox4 blk{{0u, 0u, 0u, 0u}};
-        if (SHARED && need_philox) blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
+        if (SHARED && need_philox) blk = lane_block(P, (P.lane_offset + i0) >> 2, block_tick<SLIP>(tick), 0u);
         uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0;
         uint32_t o_rew = 0, o_term = 0, o_trunc = 0, o_code = 0, o_lo = 0, o_hi = 0, f_lo = 0, f_hi = 0, fin_mask = 0;
 #pragma unroll UNROLL
@@ -728,11 +734,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
             uint32_t w = j & 2 ? (j & 1 ? blk.w[3] : blk.w[2]) : (j & 1 ? blk.w[1] : blk.w[0]);
             if (!SHARED && need_philox) {
                 const unsigned long long gl = P.lane_offset + i0 + j;
-                const Philox4 b1 = lane_block(P, gl >> 2, tick, 0u);
+                const Philox4 b1 = lane_block(P, gl >> 2, block_tick<SLIP>(tick), 0u);
                 const uint32_t sl = (uint32_t)gl & 3u;
                 w = sl & 2u ? (sl & 1u ? b1.w[3] : b1.w[2]) : (sl & 1u ? b1.w[1] : b1.w[0]);
             }
-            Draw d = draw_from_word(w);
+            Draw d = draw_from_word<SLIP>(w, tick);
             if (EXPLICIT_U) {
                 if (IO.u_step) { const double u = sane_uniform(IO.u_step[i0 + j]); d.u = u; d.top2 = (uint32_t)(u * 4.0); }
                 if (IO.u_reset) d.reset2 = (uint32_t)(sane_uniform(IO.u_reset[i0 + j]) * 4.0);
@@ -842,7 +848,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
     const unsigned long long tick = tick_ptr ? *tick_ptr : tick_val;
     if (P.tick_out) publish_tick(P, tick, 1ull);
     // the thread's 4 lanes are exactly one Philox block; computed while the loads are in flight
-    const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, tick, 0u);
+    const Philox4 blk = lane_block(P, (P.lane_offset + i0) >> 2, block_tick<SLIP>(tick), 0u);
     uint32_t nra = 0, nca = 0, nrb = 0, ncb = 0, nps = 0, ntt = 0, o_rew = 0, o_term = 0, o_trunc = 0, o_lo = 0, o_hi = 0;
     uint32_t posA[4] = {0u, 0u, 0u, 0u}, posB[4] = {0u, 0u, 0u, 0u};   // UNROLL == 4 only
     bool mis = false;
@@ -857,7 +863,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
         L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = __builtin_amdgcn_ubfe(tt, sh, 8u);
         StepResult R;
         const uint32_t a_now = __builtin_amdgcn_ubfe(aa, sh, 8u), b_now = __builtin_amdgcn_ubfe(ab, sh, 8u);
-        mis |= lane_step<SLIP, true, INT_ONLY>(T, P, L, a_now, b_now, draw_from_word(w), R);
+        mis |= lane_step<SLIP, true, INT_ONLY>(T, P, L, a_now, b_now, draw_from_word<SLIP>(w, tick), R);
         if constexpr (UNROLL == 4) { posA[j] = L.A; posB[j] = L.B; }    // rows / columns gathered with v_perm after the loop
         else {
             nra = __builtin_amdgcn_alignbyte(L.A >> 24, nra, 1); nca = __builtin_amdgcn_alignbyte((L.A >> 16) & 0xffu, nca, 1);
@@ -937,51 +943,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsign
 // Takes every Philox-driven, dword-aligned step of a slip_prob == 0 handle whose pitch fits the byte arithmetic
 // (swar::fits: every golden pitch up to 11x7 does).  GENERAL = false is the steady state of an auto-resetting
 // handle (no frozen lane, no lane in a goal tuple); FULL adds final_obs and prob_code (VectorSoccerEnv).
-// Slips with a near-integer scaled threshold (slip_int == 2: 0.1, 0.9, 0.15, 0.4 ...): the integer slip decision is exact for
-// every draw except the <= 4 integers m in KernelParams::danger (probability 2^-30 each).  A thread one of whose lanes
-// drew such an m steps its four lanes one by one through lane_step — whose WORD form walks the float64 running sums for
-// exactly those draws — and hands the results back in the packed form of swar::step4, so the rest of the kernel is shared.
-__device__ __forceinline__ bool danger_hit(const KernelParams& P, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
-    bool hit = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t d = P.danger[k];
-        hit |= ((w0 >> 2) == d) | ((w1 >> 2) == d) | ((w2 >> 2) == d) | ((w3 >> 2) == d);
-    }
-    return hit;
-}
-// (Inlined into the SLIPM == 2 instantiations only, whose register budget it sets: 140-200 VGPRs.  As a real call —
-// noinline, the kernels capped at 128 VGPRs — those kernels measured slower still: 8.2 vs 6.3 us per step launch.)
-__device__ __forceinline__ void slow_group4(const KernelParams& P, swar::Group& S, uint32_t aa, uint32_t ab, uint32_t w0, uint32_t w1,
-                                                      uint32_t w2, uint32_t w3, swar::Out& o) {
-    Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
-    const uint32_t w[4] = {w0, w1, w2, w3};
-    swar::Group N{0u, 0u, 0u, 0u, 0u, 0u};
-    o.obs_lo = 0u; o.obs_hi = 0u; o.fin_lo = 0u; o.fin_hi = 0u; o.rew = 0u; o.term = 0u; o.trunc = 0u; o.code = 0u;
-    o.finished = 0u; o.frozen = 0u;
-    const uint32_t ca = swar::canon4(aa), cb = swar::canon4(ab);
-    o.bad_action = (ca ^ aa) | (cb ^ ab);
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t sh = 8u * (uint32_t)j;
-        Lane L;
-        L.A = make_pos((S.ra >> sh) & 0xffu, (S.ca >> sh) & 0xffu, P.W);
-        L.B = make_pos((S.rb >> sh) & 0xffu, (S.cb >> sh) & 0xffu, P.W);
-        const uint32_t psj = (S.ps >> sh) & 0xffu;
-        L.p = psj & 1u; L.need = (psj >> 1) & 1u; L.t = (S.tt >> sh) & 0xffu;
-        StepResult R;
-        const bool frozen = lane_step<true, true, false>(T, P, L, (ca >> sh) & 0xffu, (cb >> sh) & 0xffu, draw_from_word(w[j]), R);
-        N.ra |= (L.A >> 24) << sh; N.ca |= ((L.A >> 16) & 0xffu) << sh;
-        N.rb |= (L.B >> 24) << sh; N.cb |= ((L.B >> 16) & 0xffu) << sh;
-        N.ps |= (L.p | (L.need << 1)) << sh; N.tt |= L.t << sh;
-        o.rew |= ((uint32_t)R.reward & 0xffu) << sh; o.term |= R.term << sh; o.trunc |= R.trunc << sh; o.code |= R.code << sh;
-        o.finished |= (R.finished ? 0x80u : 0u) << sh; o.frozen |= (frozen ? 0x80u : 0u) << sh;
-        if (j < 2) { o.obs_lo |= R.obs << (16 * j); o.fin_lo |= R.final_obs << (16 * j); }
-        else { o.obs_hi |= R.obs << (16 * (j - 2)); o.fin_hi |= R.final_obs << (16 * (j - 2)); }
-    }
-    S = N;
-}
-
 struct SwarParams {
     swar::Consts C;
     uint32_t key0, key1;
@@ -989,40 +950,43 @@ struct SwarParams {
     unsigned long long first;               // first lane (within the handle) this launch covers; multiple of 4
     unsigned long long* tick_out;
     unsigned int* misuse;                   // [0] a frozen lane was stepped (:376), [1] an action byte outside 0..4 (:393)
-    unsigned long long* hist;               // FULL: episode histogram slots (SOCCER_F_STEP_STATS), or nullptr
-    swar::SlipConsts L; const swar::Quad* sub;   // SLIP: scaled cumulative weights / the nine rows of quarter thresholds
-    const KernelParams* full;               // SLIP with dangerous draws (slip_int == 2): the handle's parameters in device memory, else nullptr
+    unsigned long long* hist; uint32_t hist_mask;   // OUT == 2: episode histogram slots (SOCCER_F_STEP_STATS), or nullptr
+    swar::SlipConsts L; const swar::Quad* sub;   // SLIP: integer cumulative weights / the nine rows of quarter thresholds
     const int8_t* policy_a; const int8_t* policy_b;   // POLICY: the fixed side's int8[nS] policy (the other is nullptr)
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
-    uint8_t* prob_code; uint16_t* final_obs;
-    float* reward_a_f32; float* reward_b_f32; uint8_t* finished;      // FULL only
+    uint8_t* prob_code; uint16_t* final_obs;                          // OUT == 2
+    float* reward_a_f32; float* reward_b_f32; uint8_t* finished; int8_t* last_return;   // OUT >= 1
 };
 
-// FULL: also final_obs / prob_code (VectorSoccerEnv's info) and, when Q.hist is set, the episode histogram.
+// OUT — which outputs the instantiation can write (every pointer may still be NULL):
+//   0  obs / reward / terminated / truncated: the 8-argument batched_step (19 B per env-step)
+//   1  + reward_a_f32 / reward_b_f32 / finished / last_return: what a gym-style loop reads every step, without the `info`
+//      extras (VectorSoccerEnv(io="device", info=False): 27 B per env-step when the int8 reward stream is left out)
+//   2  + final_obs / prob_code and, when Q.hist is set, the episode histogram (VectorSoccerEnv's info; 31 B)
 // Launch shape (tools/swar_sweep.sh, profiles/r02_sweep.md): one 4-lane group per thread with non-temporal dword
 // accesses measured best; 8 or 16 lanes per thread (dwordx2 / dwordx4), plain or write-through stores and 512-thread
 // workgroups were all equal or slower, and an instantiation without the frozen-lane / goal-tuple code was not faster
 // (the kernel is bound by launch + memory latency, not by vector issue any more).
-// SLIP: handles with slip_prob > 0 whose integer slip decision is exact for every draw (SlipTables::swar_ok): each lane
-// counts the scaled cumulative weights and its combination's quarter points below its draw (the threshold rows are
-// gathered while the state loads are still in flight: they depend on the random word only), the rest stays byte-parallel.
+// SLIP: handles with slip_prob > 0 whose integer slip decision is the reference's for every draw (SlipTables::swar_ok):
+// each lane counts the integer cumulative weights and its combination's quarter points below its draw (the threshold rows
+// are gathered while the state loads are still in flight: they depend on the random word only), the rest stays byte-parallel.
+// Without SLIP the thread's block is the one of tick >> 3 and the lanes' draws are this tick's nibbles (swar::rand_nibble).
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the observation of
 // the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
-// SLIPM: 0 slip_prob == 0; 1 the integer slip decision is exact for every draw; 2 exact except for the handle's dangerous
-// draws (slow_group4).
-template <bool FULL, int SLIPM = 0, bool POLICY = false, int GEO = 0>
+template <int OUT, bool SLIP = false, bool POLICY = false, int GEO = 0>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
                                                            const unsigned long long* tick_in,
                                                            unsigned long long n, unsigned long long tick_val,
                                                            const SwarParams Q) {
+    constexpr bool FULL = OUT == 2;
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     const bool active = (g << 2) < n;                                // n is a multiple of 4 here
     if (!FULL && !active) return;
     HistAcc<true> hist;
     const bool stats = FULL && Q.hist != nullptr;                    // wave-uniform
     if (FULL) { hist.fin = 0u; hist.pos = 0u; hist.neg = 0u; hist.old01 = make_ulonglong2(0ull, 0ull); hist.old2 = 0ull; }
-    if (stats) hist.init_at(Q.hist);
+    if (stats) hist.init_at(Q.hist, Q.hist_mask);
     if (active) {
         const unsigned long long i0 = Q.first + (g << 2);
         const uint8_t* sp = state_in + i0;
@@ -1040,7 +1004,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         const unsigned long long tick = tick_in ? *tick_in : tick_val;
         if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
         const unsigned long long q = (Q.lane_offset + i0) >> 2;     // the thread's 4 lanes are exactly one Philox block
-        const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), Q.key0, Q.key1);
+        const unsigned long long bt = block_tick<SLIP>(tick);
+        const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), Q.key0, Q.key1);
         if (POLICY) {                                               // the fixed side acts on the current observation (:187-188)
             uint32_t s_lo, s_hi;
             const uint32_t cc0 = swar::bfi(swar::mask_of(S.ps << 7), S.cb, S.ca);
@@ -1051,14 +1016,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
             if (Q.policy_a) aa = act; else ab = act;
         }
         swar::Out o;
-        uint32_t sa = 0u, sb = 0u, k4 = 0u, cls4 = 0u;
-        constexpr bool SLIP = SLIPM != 0;
-        if (SLIPM == 2 && danger_hit(*Q.full, blk.w[0], blk.w[1], blk.w[2], blk.w[3])) {      // p = 2^-28 per thread
-            slow_group4(*Q.full, S, aa, ab, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        uint32_t sa = 0u, sb = 0u, cls4 = 0u;
+        swar::Rand4 rnd;
+        if (SLIP) {
+            uint32_t k4 = 0u;
+            swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+            rnd = swar::Rand4{k4 << 6, swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> Q.C.isd_shift};
         } else {
-            if (SLIP) swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
-            swar::step4<true, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+            rnd = swar::rand_nibble(Q.C.isd_shift, (uint32_t)tick & 7u, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
         }
+        swar::step4<true, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, cls4, rnd, o);
         uint8_t* sw = const_cast<uint8_t*>(sp);
         __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
         __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(sw + state_stride));
@@ -1071,10 +1038,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         if (Q.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(Q.reward + i0));
         if (Q.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(Q.terminated + i0));
         if (Q.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(Q.truncated + i0));
-        if (FULL) {
-            if (Q.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(Q.prob_code + i0));
-            if (Q.final_obs) __builtin_nontemporal_store((unsigned long long)o.fin_lo | ((unsigned long long)o.fin_hi << 32),
-                                                         reinterpret_cast<unsigned long long*>(Q.final_obs + i0));
+        if (OUT >= 1) {
             if (Q.reward_a_f32 || Q.reward_b_f32) {                 // the rewards as the floats a gym caller reads (:400-402)
                 const int32_t r = (int32_t)o.rew;
                 const float f0 = (float)((r << 24) >> 24), f1 = (float)((r << 16) >> 24), f2 = (float)((r << 8) >> 24), f3 = (float)(r >> 24);
@@ -1084,6 +1048,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
                                       __builtin_nontemporal_store(vb, reinterpret_cast<f4*>(Q.reward_b_f32 + i0)); }
             }
             if (Q.finished) __builtin_nontemporal_store(o.term | o.trunc, reinterpret_cast<uint32_t*>(Q.finished + i0));
+            // A's return of the episode that just ended = the reward of its last step (only that step can carry one);
+            // lanes whose episode goes on keep what the stream holds.  Rare: one read-modify-write of the thread's own dword.
+            if (Q.last_return && (o.finished & swar::K80)) {
+                uint32_t* lr = reinterpret_cast<uint32_t*>(Q.last_return + i0);
+                *lr = swar::bfi(swar::mask_of(o.finished), o.rew, *lr);
+            }
+        }
+        if (FULL) {
+            if (Q.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(Q.prob_code + i0));
+            if (Q.final_obs) __builtin_nontemporal_store((unsigned long long)o.fin_lo | ((unsigned long long)o.fin_hi << 32),
+                                                         reinterpret_cast<unsigned long long*>(Q.final_obs + i0));
             // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends the episode
             if (stats) hist.add_totals((uint32_t)__builtin_popcount(o.finished & swar::K80),
                                        (int32_t)__builtin_popcount(o.rew & swar::K01) - 2 * (int32_t)__builtin_popcount(o.rew & swar::K80),
@@ -1092,13 +1067,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         if (o.frozen) Q.misuse[0] = 1u;
         if (o.bad_action) Q.misuse[1] = 1u;
     }
-    if (stats) hist.flush_at(Q.hist);
+    if (stats) hist.flush_at(Q.hist, Q.hist_mask);
 }
 
 // =================================================================================================
 // batched_reset
 // =================================================================================================
-template <bool LUT_LDS>
+template <bool LUT_LDS, bool SLIP>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const KernelParams P, const ResetIO IO) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const Tables T = stage_tables<LUT_LDS>(P, smem);
@@ -1112,7 +1087,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const KernelParams P, con
         if (sel) {
             uint32_t bits;
             if (IO.u_reset) bits = (uint32_t)(sane_uniform(IO.u_reset[i]) * 4.0);
-            else { uint32_t w[1]; lane_words<1>(P, P.lane_offset + i, tick, 0u, w); bits = w[0] & 3u; }
+            else { uint32_t w[1]; lane_words<1>(P, P.lane_offset + i, block_tick<SLIP>(tick), 0u, w); bits = draw_from_word<SLIP>(w[0], tick).reset2; }
             LaneVec<1> S; lane_reset(T, P, S.L[0], bits, ob);
             S.store(P, i);
         } else if (IO.obs) {
@@ -1133,7 +1108,7 @@ struct ResetSwar {
     uint32_t key0, key1;
     const uint8_t* mask; uint16_t* obs;
 };
-template <bool MASKED>
+template <bool MASKED, bool SLIP>
 __global__ __launch_bounds__(kBlock) void reset_kernel_swar(const ResetSwar R) {
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     const unsigned long long i0 = g << 2;
@@ -1150,9 +1125,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel_swar(const ResetSwar R) {
     const unsigned long long tick = *R.tick_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *R.tick_out = tick + 1ull;
     const unsigned long long q = (R.lane_offset + i0) >> 2;
-    const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
+    const unsigned long long bt = block_tick<SLIP>(tick);
+    const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), R.key0, R.key1);
     uint32_t o_lo, o_hi;
-    swar::reset4<MASKED>(R.C, S, mask4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o_lo, o_hi);
+    const swar::Rand4 rnd = SLIP ? swar::rand_words(R.C.isd_shift, blk.w[0], blk.w[1], blk.w[2], blk.w[3])
+                                 : swar::rand_nibble(R.C.isd_shift, (uint32_t)tick & 7u, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
+    swar::reset4<MASKED>(R.C, S, mask4, rnd, o_lo, o_hi);
     *reinterpret_cast<uint32_t*>(sp) = S.ra; *reinterpret_cast<uint32_t*>(sp + R.state_stride) = S.ca;
     *reinterpret_cast<uint32_t*>(sp + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sp + 3 * R.state_stride) = S.cb;
     *reinterpret_cast<uint32_t*>(sp + 4 * R.state_stride) = S.ps; *reinterpret_cast<uint32_t*>(sp + 5 * R.state_stride) = S.tt;
@@ -1257,13 +1235,13 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
             bad_act |= canon_pack(naa) | canon_pack(nab);
         }
         uint32_t words[E], awords[E];
-        lane_words<E>(P, P.lane_offset + i0, tick, 0u, words);
+        lane_words<E>(P, P.lane_offset + i0, block_tick<SLIP>(tick), 0u, words);
         if (sample) lane_words<E>(P, P.lane_offset + i0, tick, 1u, awords);
         PackB<E> o_rew, o_term, o_trunc; PackH<E> o_obs;
         o_rew.clear(); o_term.clear(); o_trunc.clear(); o_obs.clear();
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const Draw d = draw_from_word(words[j]);
+            const Draw d = draw_from_word<SLIP>(words[j], tick);
             uint32_t a = aa.get(j), b = ab.get(j);
             if (sample) {                               // two actions from one 32-bit word, 15 bits each
                 const uint32_t ha = awords[j] & 0x7fffu, hb = (awords[j] >> 16) & 0x7fffu;
@@ -1348,43 +1326,52 @@ struct RolloutSwar {       // everything the kernel needs, and nothing else (Ker
     const int8_t* policy_a; const int8_t* policy_b;
     uint32_t key0, key1;
     swar::Consts C; swar::SlipConsts L; const swar::Quad* sub;
-    const KernelParams* full;               // slip_int == 2 handles: see slow_group4
+    uint32_t hist_mask;
     int32_t nS; int32_t lds_tables;
 };
 
-// number of a mixed-policy row's four 16-bit cumulative thresholds (values 0..2^15) that are <= the 15-bit draw h: both
-// halves of a dword at once — (h + 0x8000) - t has bit 15 set exactly when h >= t — and one population count
-__device__ __forceinline__ uint32_t count_le15(uint32_t h, uint2 th) {
+// number of a mixed-policy row's four 16-bit cumulative thresholds (values 0..2^15) that are <= a 15-bit draw h.  `hs`
+// holds h in both halves with bit 15 set: (h + 0x8000) - t has bit 15 set exactly when h >= t, two thresholds per
+// packed subtraction, one population count for the four of them.
+__device__ __forceinline__ uint32_t count_le15(uint32_t hs, uint32_t tx, uint32_t ty) {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const uint32_t hs = __umul24(h, 0x10001u) | 0x80008000u;
-    const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, th.x));
-    const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, th.y));
+    const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, tx));
+    const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, ty));
     return (uint32_t)__builtin_popcount((x & 0x80008000u) | ((y >> 1) & 0x40004000u));
 }
+// the two 15-bit action draws of a lane's purpose-1 word (da = w & 0x7fff, db = (w >> 16) & 0x7fff), each duplicated
+// into both halves with bit 15 forced: one byte permute + one OR per player
+__device__ __forceinline__ uint32_t draw_a15(uint32_t w) { return swar::perm(0u, w, 0x01000100u) | 0x80008000u; }
+__device__ __forceinline__ uint32_t draw_b15(uint32_t w) { return swar::perm(0u, w, 0x03020302u) | 0x80008000u; }
 
 // the T steps of one thread's four lanes.  GENERAL = false: no lane is frozen or in a goal tuple on entry and the handle
 // auto-resets, so none ever will be (the steady state): the step's code for those cases is compiled out.
 // DYNM — where the actions come from: 0 both from the action streams; 1 both sampled uniformly in the kernel; 2 both
-// sampled from mixed-policy tables (config 5); 4 / 5 player A / B follows its fixed policy and the other side's actions
-// are streamed (single-agent mode); 3 anything else (a table on one side only, a fixed policy against a sampled side ...:
-// decided by wave-uniform run-time tests).  The common shapes are instantiations of their own because every optional
-// pointer that stays live costs scalar registers, and the loop of the catch-all form spilled them (60-300 v_readlane_b32
-// per step).
-template <int DYNM, int SLIPM, bool GENERAL, int GEO>
+// sampled from mixed-policy tables staged in LDS as one 16-byte row per state (config 5); 4 / 5 player A / B follows its
+// fixed policy and the other side's actions are streamed (single-agent mode); 3 anything else (a table on one side only,
+// tables too big for LDS, a fixed policy against a sampled side ...: decided by wave-uniform run-time tests).  The common
+// shapes are instantiations of their own because every optional pointer that stays live costs scalar registers, and the
+// loop of the catch-all form spilled them (60-300 v_readlane_b32 per step).
+// Randomness (include/soccer_hip.h): with SLIP one step/reset block per tick; without, one block per EIGHT ticks — the
+// thread keeps it transposed (swar::transpose4) in p0..p3, p0 serving the current pair of ticks — which takes the Philox
+// rounds from ~45 to ~6 vector instructions per step; sampled actions take the lane's word of the tick's purpose-1 block.
+template <int DYNM, bool SLIP, bool GENERAL, int GEO>
 __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const swar::Quad* sub,
                                                    const uint2* mix_a_in, const uint2* mix_b_in, const int8_t* pol_a_in, const int8_t* pol_b_in,
                                                    unsigned long long i0, unsigned long long tick0, swar::Group& S,
                                                    uint32_t& fin_tot, uint32_t& nz_tot, uint32_t& neg_tot,
                                                    uint32_t (&acc)[4], uint32_t& frozen_any, uint32_t& bad_any) {
     constexpr bool DYN = DYNM != 0;
+    constexpr bool TRUSTED = DYNM == 1 || DYNM == 2;                    // both sides sampled in 0..4 by the kernel itself
     const bool sample = DYNM == 1 || DYNM == 2 || (DYNM == 3 && IO.sample_actions);
-    const uint2* mix_a = DYNM == 2 || DYNM == 3 ? mix_a_in : nullptr;
-    const uint2* mix_b = DYNM == 2 || DYNM == 3 ? mix_b_in : nullptr;
+    const uint4* mix_ab = DYNM == 2 ? reinterpret_cast<const uint4*>(mix_a_in) : nullptr;   // LDS rows { a: x, y; b: z, w }
+    const uint2* mix_a = DYNM == 3 ? mix_a_in : nullptr;
+    const uint2* mix_b = DYNM == 3 ? mix_b_in : nullptr;
     const int8_t* pol_a = DYNM == 3 || DYNM == 4 ? pol_a_in : nullptr;
     const int8_t* pol_b = DYNM == 3 || DYNM == 5 ? pol_b_in : nullptr;
     const bool use_pol_a = DYNM == 4 || (DYNM == 3 && pol_a != nullptr), use_pol_b = DYNM == 5 || (DYNM == 3 && pol_b != nullptr);
-    const bool use_mix_a = DYNM == 2 || (DYNM == 3 && sample && mix_a != nullptr);
-    const bool use_mix_b = DYNM == 2 || (DYNM == 3 && sample && mix_b != nullptr);
+    const bool use_mix_a = DYNM == 3 && sample && mix_a != nullptr;
+    const bool use_mix_b = DYNM == 3 && sample && mix_b != nullptr;
     const bool load_a = DYNM == 0 || DYNM == 5 || (DYNM == 3 && !sample && IO.act_a != nullptr);
     const bool load_b = DYNM == 0 || DYNM == 4 || (DYNM == 3 && !sample && IO.act_b != nullptr);
     const bool lane_acc = IO.return_sum != nullptr || IO.episode_count != nullptr;
@@ -1399,6 +1386,13 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         swar::obs4<true>(R.C, S.ra, S.ca, S.rb, S.cb, S.ps & swar::K01, swar::is_zero(cc0) | swar::is_zero(cc0 ^ R.C.Wm1x4), s_lo, s_hi);
     }
     const unsigned long long q = (R.lane_offset + i0) >> 2;
+    uint32_t p0 = 0u, p1 = 0u, p2 = 0u, p3 = 0u;                        // !SLIP: the current eight-tick block, transposed
+    if (!SLIP) {
+        const unsigned long long bt = tick0 >> 3;
+        const Philox4 b = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), R.key0, R.key1);
+        swar::transpose4(b.w[0], b.w[1], b.w[2], b.w[3], p0, p1, p2, p3);
+        for (uint32_t r = ((uint32_t)tick0 & 7u) >> 1; r != 0u; --r) { p0 = p1; p1 = p2; p2 = p3; }   // wave-uniform
+    }
     for (int s = 0; s < IO.n_steps; ++s) {
         const unsigned long long tick = tick0 + (unsigned long long)s;
         uint32_t naa = aa, nab = ab;
@@ -1406,7 +1400,6 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             if (load_a) naa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)(s + 1) * IO.act_stride + i0));
             if (load_b) nab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)(s + 1) * IO.act_stride + i0));
         }
-        const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
         uint32_t a4 = aa, b4 = ab;
         if (DYN) {
             uint32_t aw[4] = {0u, 0u, 0u, 0u};
@@ -1418,11 +1411,15 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t ob = ((j & 2 ? s_hi : s_lo) >> (16 * (j & 1))) & 0xffffu;
-                if (sample) {                       // two actions from one 32-bit word, 15 bits each
+                if (DYNM == 2) {                    // both sides from their tables: one 16-byte LDS row per lane
+                    const uint4 th = mix_ab[ob];
+                    a4 |= count_le15(draw_a15(aw[j]), th.x, th.y) << (8 * j);
+                    b4 |= count_le15(draw_b15(aw[j]), th.z, th.w) << (8 * j);
+                } else if (sample) {                // two actions from one 32-bit word, 15 bits each
                     const uint32_t ha = aw[j] & 0x7fffu, hb = (aw[j] >> 16) & 0x7fffu;
                     uint32_t a = (ha * 5u) >> 15, b = (hb * 5u) >> 15;          // uniform
-                    if (use_mix_a) a = count_le15(ha, mix_a[ob]);
-                    if (use_mix_b) b = count_le15(hb, mix_b[ob]);
+                    if (use_mix_a) { const uint2 th = mix_a[ob]; a = count_le15(draw_a15(aw[j]), th.x, th.y); }
+                    if (use_mix_b) { const uint2 th = mix_b[ob]; b = count_le15(draw_b15(aw[j]), th.x, th.y); }
                     a4 |= a << (8 * j); b4 |= b << (8 * j);
                 }
                 if (use_pol_a) a4 = (a4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_a[ob] << (8 * j));
@@ -1430,14 +1427,24 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             }
         }
         swar::Out o;
-        uint32_t sa = 0u, sb = 0u, k4 = 0u, cls4 = 0u;
-        constexpr bool SLIP = SLIPM != 0;
-        if (SLIPM == 2 && danger_hit(*R.full, blk.w[0], blk.w[1], blk.w[2], blk.w[3])) {
-            slow_group4(*R.full, S, a4, b4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+        uint32_t sa = 0u, sb = 0u, cls4 = 0u;
+        swar::Rand4 rnd;
+        if (SLIP) {
+            const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
+            uint32_t k4 = 0u;
+            swar::slip_select4(R.L, sub, TRUSTED ? a4 : swar::canon4(a4), TRUSTED ? b4 : swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+            rnd = swar::Rand4{k4 << 6, swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> R.C.isd_shift};
         } else {
-            if (SLIP) swar::slip_select4(R.L, sub, swar::canon4(a4), swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
-            swar::step4<GENERAL, false, SLIP, GEO>(R.C, S, a4, b4, sa, sb, k4, cls4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], o);
+            const uint32_t t = (uint32_t)tick & 7u;                     // wave-uniform, like everything that steers this block
+            if (t == 0u && s != 0) {
+                const unsigned long long bt = tick >> 3;
+                const Philox4 b = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), R.key0, R.key1);
+                swar::transpose4(b.w[0], b.w[1], b.w[2], b.w[3], p0, p1, p2, p3);
+            }
+            rnd = swar::rand_pair(R.C.isd_shift, t, p0);
+            if (t & 1u) { p0 = p1; p1 = p2; p2 = p3; }
         }
+        swar::step4<GENERAL, false, SLIP, GEO, TRUSTED>(R.C, S, a4, b4, sa, sb, cls4, rnd, o);
         s_lo = o.obs_lo; s_hi = o.obs_hi;
         const long long off = (long long)s * IO.out_stride + (long long)i0;
         if (IO.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
@@ -1456,18 +1463,18 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             acc[2] += swar::perm(0u, f01, 0x0c010c00u); acc[3] += swar::perm(0u, f01, 0x0c030c02u);   // <= 4096 < 2^16: no carry
         }
         if (GENERAL) frozen_any |= o.frozen;
-        bad_any |= o.bad_action;
+        if (!TRUSTED) bad_any |= o.bad_action;
         aa = naa; ab = nab;
     }
 }
 
-template <int DYNM, int SLIPM, int GEO = 0>
+template <int DYNM, bool SLIP, int GEO = 0>
 __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar R, const RolloutIO IO) {
-    constexpr bool SLIP = SLIPM != 0;
     constexpr bool DYN = DYNM >= 2;          // the forms that look something up by the observation
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    HistAcc<false> hist; hist.init_at(R.hist);
-    // LDS: [0, 36) the nine threshold rows (SLIP), then (DYN, when they fit) mix_a, mix_b rows (8 B per state) and the
+    HistAcc<false> hist; hist.init_at(R.hist, R.hist_mask);
+    // LDS: [0, 36) the nine threshold rows (SLIP), then (DYN, when they fit) the mixed-policy rows — DYNM == 2: one 16-byte
+    // row { a's four thresholds, b's four } per state; DYNM == 3: mix_a rows, then mix_b rows (8 B per state) — and the
     // two fixed policies (1 B per state)
     const swar::Quad* sub = R.sub;
     const uint2* mix_a = reinterpret_cast<const uint2*>(IO.mix_a);
@@ -1477,7 +1484,11 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
     if (SLIP || (DYN && R.lds_tables)) {
         if (SLIP) { if (threadIdx.x < 36) smem[threadIdx.x] = reinterpret_cast<const uint32_t*>(R.sub)[threadIdx.x];
                     sub = reinterpret_cast<const swar::Quad*>(smem); }
-        if (DYN && R.lds_tables) {
+        if (DYNM == 2) {                     // the host picks this shape only when the rows fit
+            uint4* lab = reinterpret_cast<uint4*>(smem + 36);
+            for (int i = threadIdx.x; i < R.nS; i += kBlock) { const uint2 xa = mix_a[i], xb = mix_b[i]; lab[i] = make_uint4(xa.x, xa.y, xb.x, xb.y); }
+            mix_a = reinterpret_cast<const uint2*>(lab); mix_b = nullptr;
+        } else if (DYN && R.lds_tables) {
             uint2* la = reinterpret_cast<uint2*>(smem + 36); uint2* lb = la + R.nS;
             int8_t* pa = reinterpret_cast<int8_t*>(lb + R.nS); int8_t* pb = pa + ((R.nS + 15) & ~15);
             if (sample && mix_a) { for (int i = threadIdx.x; i < R.nS; i += kBlock) la[i] = mix_a[i]; mix_a = la; }
@@ -1504,8 +1515,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
         const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
         const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
-        if (special) rollout_swar_group<DYNM, SLIPM, true, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
-        else rollout_swar_group<DYNM, SLIPM, false, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        if (special) rollout_swar_group<DYNM, SLIP, true, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYNM, SLIP, false, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
         uint8_t* sw = R.state + i0;
         *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
         *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;
@@ -1520,7 +1531,7 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
     }
     if (frozen_any) R.misuse[0] = 1u;
     if (bad_any) R.misuse[1] = 1u;
-    hist.flush_at(R.hist);
+    hist.flush_at(R.hist, R.hist_mask);
 }
 
 // =================================================================================================

@@ -1,9 +1,27 @@
 // soccer_slip.hpp — host-side construction of the slip-combination weights and thresholds (reference
 // gym_soccer/envs/soccer_simultaneous_env.py:202-227, :241).  Host-only; shared by libsoccer_hip.so (soccer_create) and
 // the CPU test harness of the byte-parallel step (tests/host/swar_host.cpp).
+//
+// What the kernels need to know about a slip_prob > 0 handle is where a draw falls in the (state, joint action) list the
+// reference samples from (:395): the list holds, for each of the nine slip combinations with a non-zero weight (:209-227)
+// in order, 1, 2 or 4 entries of probability weight * {1, .5, .25} (:241), and gym's categorical_sample picks the first
+// entry whose SEQUENTIAL float64 running sum exceeds u.  A Philox draw is u = (m + 1/2) * 2^-30 with an integer m < 2^30
+// (include/soccer_hip.h), so "running sum t <= u"  <=>  t * 2^30 - 1/2 <= m  <=>  m >= ceil(t * 2^30 - 1/2), and both the
+// scaling and the subtraction are exact in float64: the decision is an integer comparison with c(t) = ceil(t * 2^30 - 1/2).
+// The running sum t at a given entry depends on the SHAPE of the list before it (a combination that contributes four
+// quarter entries does not always round like one that contributes a single entry), so build_slip_tables() walks every
+// shape — at most 3^8 prefixes, a few dozen distinct running sums in practice — and accepts the integer decision only if
+// c(t) is the same for every shape at every entry position.  It then IS the reference's decision for every draw of every
+// lane; nothing is left to a margin.  (Round 2 compared u = m * 2^-30 against nominal thresholds with a 2^-40 safety
+// margin: decimal slips such as 0.1 put mathematically dyadic thresholds like 27/32 exactly on a draw, where the float64
+// rounding of the particular list decides — those handles needed a float64 walk inside the kernels.  With the half-step
+// offset no draw can sit on such a threshold, and of 9 999 slips k / 10 000 and 2 016 fractions n / d, d <= 64, none is
+// left ambiguous; 8 and 85 were.)
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <vector>
 
 #include "soccer_swar.hpp"
 
@@ -12,18 +30,18 @@ namespace soccer {
 struct SlipTables {
     double w[4];                 // weights c0..c3 of the four combination classes, float64 exactly as :211-222 evaluates them
     double B[9];                 // cumulative weight after each ACTIVE (non-zero) combination in reference order, +inf beyond
+                                 // (nominal thresholds of the float64 fast path that serves caller-supplied uniforms)
     uint32_t nb;                 // number of active combinations
     unsigned long long act_pack; // their ids, 4 bits each
-    // Integer form of the decision for draws that come from a Philox word (u = m * 2^-30, m < 2^30): scaling a float64
-    // threshold by 2^30 is exact, so u >= b <=> m >= ceil(b * 2^30).
-    uint32_t CB[9];              // scaled B (0xFFFFFFFF beyond the active ones)
-    swar::Quad sub[9];           // per active combination: { mid-point of a two-way list, quarter points of a four-way list }, scaled
-    uint32_t slip_int;           // 0: float64 only; 1: the integer decision is exact for every draw; 2: exact except for draws in `danger`
-    uint32_t danger[4];
+    // Integer form of the decision for Philox draws (see above): entry passed  <=>  m >= c
+    uint32_t CB[9];              // c at the end of each active combination (0xFFFFFFFF beyond the active ones)
+    swar::Quad sub[9];           // per active combination: { c of the first entry of a two-way list, c of entries 1, 2, 3 of a four-way list }
+    uint32_t slip_int;           // 1: the integer decision is the reference's for every draw and every list shape; 0: it is not
+                                 // (some entry's c depends on the shape, or a draw could fall beyond the last entry): float64 walk
     uint32_t c_off;              // id of the first active combination when they are consecutive (0, or 5 when slip_prob == 1)
-    bool swar_ok;                // the byte-parallel kernels may use the integer decision: slip_int == 1 (or 2: then a thread that
-                                 // draws a dangerous integer leaves the byte-parallel path for that step), the active combinations are
-                                 // consecutive ids, and every mid-point threshold equals the second quarter point
+    bool swar_ok;                // the byte-parallel kernels may use the integer decision: slip_int == 1, the active combinations
+                                 // are consecutive ids, and a two-way list's first entry ends where a four-way list's second does
+                                 // (one quarter index then serves both)
 };
 
 inline SlipTables build_slip_tables(double slip_prob) {
@@ -37,7 +55,6 @@ inline SlipTables build_slip_tables(double slip_prob) {
         volatile double c2a = s * one_minus;  volatile double c2 = c2a * 0.5;
         volatile double c3a = s * s;          volatile double c3 = c3a * 0.25;
         T.w[0] = c0; T.w[1] = c1; T.w[2] = c2; T.w[3] = c3;
-        // nominal thresholds of the slip fast path: running sum of the active weights in list order
         volatile double acc = 0.0;
         T.nb = 0; T.act_pack = 0;
         for (int c = 0; c < 9; ++c) T.B[c] = __builtin_inf();
@@ -48,76 +65,51 @@ inline SlipTables build_slip_tables(double slip_prob) {
             T.B[T.nb] = acc; T.act_pack |= (unsigned long long)c << (4 * T.nb); ++T.nb;
         }
     }
-    // Allowed only if no scaled threshold lies within 2^-10 of an integer (then no draw can be within 2^-40 of a
-    // threshold and the nominal decision is the exact one) and the last cumulative weight exceeds every possible draw.
-    bool ok = slip_prob != 0.0 && T.nb >= 1;
-    uint32_t danger[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; int n_danger = 0;
-    // Dyadic slips (0.5, 0.25, 0.75, 1.0 ...): every weight is a short binary fraction and every float64 sum of the
-    // lists is EXACT, so the nominal thresholds ARE the running sums and the integer comparison is the reference's
-    // comparison even when a draw sits exactly on a threshold.  Checked with error-free sums.
-    bool exact = true;
-    auto add_exact = [&](double a, double b) {                          // Fast2Sum: the rounding error of a + b
-        volatile double sum = a + b; volatile double bb = sum - a; volatile double err = (a - (sum - bb)) + (b - bb);
-        if (err != 0.0) exact = false;
-        return (double)sum;
-    };
-    {
-        double acc = 0.0;
-        for (int c = 0; c < 9; ++c) {
-            const double wc = T.w[cls[c]];
-            if (wc == 0.0) continue;
-            double t2 = acc; for (int j = 0; j < 2; ++j) t2 = add_exact(t2, wc * 0.5);     // .5/.5 lists
-            double t4 = acc; for (int j = 0; j < 4; ++j) t4 = add_exact(t4, wc * 0.25);    // .25 x 4 lists
-            acc = add_exact(acc, wc);
-            if (t2 != acc || t4 != acc) exact = false;
-        }
-        volatile double s1 = slip_prob; volatile double om = 1 - s1;
-        if (add_exact(om, s1) != 1.0) exact = false;
-        // the weight products themselves must be exact too: compare with long double
-        const long double S = slip_prob, O = 1.0L - S;
-        if ((long double)T.w[0] != O * O || (long double)T.w[1] != O * S * 0.5L || (long double)T.w[2] != S * O * 0.5L ||
-            (long double)T.w[3] != S * S * 0.25L || (long double)(double)O != O) exact = false;
-    }
-    auto scaled = [&](double t, uint32_t& out) {
-        const double x = t * 0x1.0p30;                                  // exact
-        if (!(x >= 0.0) || x > 0x1.0p31) { ok = false; out = 0xFFFFFFFFu; return; }
-        const double r = __builtin_nearbyint(x);
-        // a draw m = r (< 2^30) could sit on / next to the threshold: only safe when the sums are exact;
-        // otherwise remember r — a lane that draws it walks the float64 sums (slip_int = 2)
-        if (!exact && __builtin_fabs(x - r) < 0x1.0p-10 && r < 0x1.0p30) {
-            const uint32_t ri = (uint32_t)r;
-            bool seen = false;
-            for (int q = 0; q < n_danger && q < 4; ++q) seen = seen || danger[q] == ri;
-            if (!seen) { if (n_danger < 4) danger[n_danger] = ri; ++n_danger; }
-        }
-        out = (uint32_t)__builtin_ceil(x);
-    };
     for (int i = 0; i < 9; ++i) { T.CB[i] = 0xFFFFFFFFu; T.sub[i] = swar::Quad{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; }
+    bool ok = slip_prob != 0.0 && T.nb >= 1;
+    // c(t) = ceil(t * 2^30 - 1/2), clamped to 2^30 ("no draw reaches this entry's end": every m is below it)
+    constexpr uint32_t kNone = 0xFFFFFFFEu;
+    auto c_of = [](double t) -> uint32_t {
+        volatile double x = t * 0x1.0p30;                               // exact
+        volatile double y = x - 0.5;                                    // exact (see the header comment)
+        const double c = __builtin_ceil(y);
+        if (!(c > 0.0)) return 0u;
+        return c >= 0x1.0p30 ? (1u << 30) : (uint32_t)c;
+    };
+    auto merge = [&](uint32_t& slot, uint32_t c) { if (slot == kNone) slot = c; else if (slot != c) ok = false; };
+    std::vector<double> prefix{0.0};                                    // distinct running sums in front of combination i
     for (uint32_t i = 0; i < T.nb && i < 9; ++i) {
-        scaled(T.B[i], T.CB[i]);
-        const int c = (int)((T.act_pack >> (4 * i)) & 0xf);
-        volatile double S = i ? T.B[i - 1] : 0.0;
-        volatile double q2 = T.w[cls[c]] * 0.5, q4 = T.w[cls[c]] * 0.25;
-        volatile double a1 = S + q2;                                     // two outcomes: t1
-        volatile double b1 = S + q4; volatile double b2 = b1 + q4; volatile double b3 = b2 + q4;   // four: t1, t2, t3
-        scaled(a1, T.sub[i].x); scaled(b1, T.sub[i].y); scaled(b2, T.sub[i].z); scaled(b3, T.sub[i].w);
+        const double wc = T.w[cls[(T.act_pack >> (4 * i)) & 0xf]];
+        uint32_t end = kNone, two0 = kNone, four[3] = {kNone, kNone, kNone};
+        std::vector<double> next;
+        for (const double S : prefix) {
+            for (int n = 1; n <= 4; n <<= 1) {                          // the combination contributes 1, 2 or 4 equal entries
+                volatile double q = wc * (n == 1 ? 1.0 : (n == 2 ? 0.5 : 0.25));   // :241
+                volatile double acc = S;
+                for (int k = 0; k < n; ++k) {
+                    acc = acc + q;                                      // the sequential cumsum of categorical_sample
+                    const uint32_t c = c_of(acc);
+                    if (k == n - 1) merge(end, c);
+                    else if (n == 2) merge(two0, c);
+                    else merge(four[k], c);
+                }
+                next.push_back((double)acc);
+            }
+        }
+        std::sort(next.begin(), next.end());
+        next.erase(std::unique(next.begin(), next.end()), next.end());
+        prefix.swap(next);
+        T.CB[i] = end; T.sub[i] = swar::Quad{two0, four[0], four[1], four[2]};
     }
-    if (ok && T.CB[T.nb - 1] < (1u << 30)) ok = false;                 // some draw would fall beyond the last entry
-    T.slip_int = !ok || n_danger > 4 ? 0u : (n_danger ? 2u : 1u);
-    for (int q = 0; q < 4; ++q) T.danger[q] = danger[q];
-    // what the byte-parallel kernels additionally rely on
+    // a draw beyond the last entry's end would make categorical_sample return index 0 (argmax of all-False)
+    if (ok && T.CB[T.nb - 1] < (1u << 30)) ok = false;
+    T.slip_int = ok ? 1u : 0u;
     bool consecutive = T.nb >= 1;
     T.c_off = (uint32_t)(T.act_pack & 0xf);
     for (uint32_t i = 0; i < T.nb; ++i) consecutive = consecutive && ((T.act_pack >> (4 * i)) & 0xf) == T.c_off + i;
-    // mid-point == second quarter point, or they differ by one around a dangerous integer (then the only draw that tells
-    // them apart is that integer, which never takes the integer decision)
-    auto is_danger = [&](uint32_t m) { bool d = false; for (int q = 0; q < 4; ++q) d = d || T.danger[q] == m; return d; };
     bool mid = true;
-    for (uint32_t i = 0; i < T.nb; ++i) {
-        const uint32_t x = T.sub[i].x, z = T.sub[i].z;
-        mid = mid && (x == z || (x + 1 == z && is_danger(x)) || (z + 1 == x && is_danger(z)));
-    }
-    T.swar_ok = (T.slip_int == 1u || T.slip_int == 2u) && consecutive && mid;
+    for (uint32_t i = 0; i < T.nb; ++i) mid = mid && T.sub[i].x == T.sub[i].z;
+    T.swar_ok = T.slip_int == 1u && consecutive && mid;
     return T;
 }
 

@@ -82,6 +82,16 @@ SOCCER_HD uint32_t pk_add(uint32_t a, uint32_t b) {
 #endif
 }
 
+// v_alignbit_b32 with both inputs equal: rotate right
+SOCCER_HD uint32_t rotr(uint32_t x, uint32_t r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(x, x, r);
+#else
+    r &= 31u;
+    return r ? (x >> r) | (x << (32u - r)) : x;
+#endif
+}
+
 constexpr uint32_t K80 = 0x80808080u, K01 = 0x01010101u, K7F = 0x7f7f7f7fu;
 
 // flag word (truth in bit 7 of each byte) -> byte mask 0xff / 0x00: the sign selectors of v_perm_b32 reach the odd
@@ -172,6 +182,51 @@ inline Consts make_consts(int H, int W, int goal_lo, int goal_hi, int max_steps,
     return C;
 }
 
+// ---- the random bits of four lanes for one tick, as step4 / reset4 consume them ---------------------------------------
+//   kq: bits 7 and 6 of byte j = bits 1 and 0 of lane j's QUARTER draw floor(4u) (a flag word and its left shift);
+//       lists of probabilities 1, .5/.5 or .25 x 4 are sampled with floor(2u) / floor(4u)
+//   rs: byte j, after `& Consts::isd_mask`, = lane j's reset draw (index into the ISD, :414) — the caller has already
+//       shifted it right by Consts::isd_shift; the other bits are don't-care
+// Where the bits come from is the RNG convention of include/soccer_hip.h:
+//   slip_prob == 0  one Philox block serves a group of four lanes for EIGHT ticks: lane j of the group owns word j, tick k
+//                   uses its nibble (k & 7) ^ 1 (counted from the least significant): the nibble's two high bits are the
+//                   quarter draw, its two low bits the reset draw  (rand_nibble; the rollout walks the block with
+//                   transpose4 / rand_pair instead of rotating four words per tick)
+//   slip_prob > 0   one block per tick: lane j's word w gives m = w >> 2 (slip_select4 turns it into combination and
+//                   quarter) and the reset draw w & 3  (rand_words gives rs; kq = quarter << 6)
+struct Rand4 { uint32_t kq, rs; };
+
+// byte j of the result = byte 0 of word j
+SOCCER_HD uint32_t pack_byte0(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return perm(perm(w3, w2, 0x0c0c0400u), perm(w1, w0, 0x0c0c0400u), 0x05040100u);
+}
+// byte j of the result = byte 3 of word j
+SOCCER_HD uint32_t pack_byte3(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return perm(perm(w3, w2, 0x0c0c0703u), perm(w1, w0, 0x0c0c0703u), 0x05040100u);
+}
+// one word per lane and tick: quarter draw = the word's two top bits, reset draw = its two low bits
+SOCCER_HD Rand4 rand_words(const uint32_t isd_shift, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return Rand4{pack_byte3(w0, w1, w2, w3), pack_byte0(w0, w1, w2, w3) >> isd_shift};
+}
+// tick t (= tick & 7) of an eight-tick block: nibble t ^ 1 of each lane's word, rotated into the high nibble of byte 0
+SOCCER_HD Rand4 rand_nibble(const uint32_t isd_shift, uint32_t t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    const uint32_t r = (4u * (t ^ 1u) + 28u) & 31u;
+    const uint32_t x = pack_byte0(rotr(w0, r), rotr(w1, r), rotr(w2, r), rotr(w3, r));
+    return Rand4{x, x >> (4u + isd_shift)};
+}
+// the 128 bits of a block as four dwords p[i], byte j of p[i] = byte i of word j: p[i] serves ticks 2i (high nibbles)
+// and 2i + 1 (low nibbles) of the block's eight
+SOCCER_HD void transpose4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t& p0, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const uint32_t a = perm(w1, w0, 0x05010400u), b = perm(w1, w0, 0x07030602u);
+    const uint32_t c = perm(w3, w2, 0x05010400u), d = perm(w3, w2, 0x07030602u);
+    p0 = perm(c, a, 0x05040100u); p1 = perm(c, a, 0x07060302u); p2 = perm(d, b, 0x05040100u); p3 = perm(d, b, 0x07060302u);
+}
+// the draws of tick t from the transposed dword that holds its pair of ticks: even ticks read the high nibbles
+SOCCER_HD Rand4 rand_pair(const uint32_t isd_shift, uint32_t t, uint32_t p) {
+    const uint32_t sh = (t & 1u) << 2;
+    return Rand4{p << sh, p >> (4u - sh + isd_shift)};
+}
+
 // four lanes of the six state streams
 struct Group { uint32_t ra, ca, rb, cb, ps, tt; };
 
@@ -226,9 +281,9 @@ SOCCER_HD void move4(const Consts& C, uint32_t r, uint32_t c, uint32_t mv, uint3
 }
 
 // ---- slip: which of the nine combinations a lane's draw selects, and where in it the draw falls -------------------
-// (:202-227, :241, :395) for draws that come from a Philox word, u = m * 2^-30 with m = w >> 2: the integer form of the
+// (:202-227, :241, :395) for draws that come from a Philox word, u = (m + 1/2) * 2^-30 with m = w >> 2: the integer form of the
 // first-exceeds rule over the list's running sums (soccer_slip.hpp builds and checks the scaled thresholds).
-struct alignas(16) Quad { uint32_t x, y, z, w; };    // per combination: scaled { mid-point, quarter points 1, 2, 3 } of its mass
+struct alignas(16) Quad { uint32_t x, y, z, w; };    // per combination: integer thresholds { mid-point, quarter points 1, 2, 3 } of its mass
 struct SlipConsts {
     uint32_t CB[9];        // scaled cumulative weight after each active combination (0xFFFFFFFF beyond)
     uint32_t c_off;        // id of the first active combination (0; 5 when slip_prob == 1)
@@ -289,13 +344,11 @@ SOCCER_HD void obs4(const Consts& C, uint32_t r_a, uint32_t c_a, uint32_t r_b, u
 }
 
 // reset (:410-424) of four lanes: every lane (MASKED = false: nothing is read) or the lanes whose mask byte is non-zero.
-// The ISD entry is drawn with the two low bits of the lane's random word, as in the in-step reset; lanes that are not
+// The ISD entry is drawn with the lane's reset draw (Rand4::rs), as in the in-step reset; lanes that are not
 // selected keep their state and report the observation of the tuple they hold (goal tuples: 0).
 template <bool MASKED>
-SOCCER_HD void reset4(const Consts& C, Group& S, uint32_t mask4, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
-                      uint32_t& obs_lo, uint32_t& obs_hi) {
-    const uint32_t y01 = perm(w1, w0, 0x0c0c0400u), y23 = perm(w3, w2, 0x0c0c0400u);
-    const uint32_t idx = (perm(y23, y01, 0x05040100u) >> C.isd_shift) & C.isd_mask;
+SOCCER_HD void reset4(const Consts& C, Group& S, uint32_t mask4, const Rand4& R, uint32_t& obs_lo, uint32_t& obs_hi) {
+    const uint32_t idx = R.rs & C.isd_mask;
     const uint32_t ira = perm(0u, C.isd_ra, idx), irb = perm(0u, C.isd_rb, idx), ip = perm(0u, C.isd_p, idx);
     uint32_t zero7 = 0u;
     if (MASKED) {
@@ -319,15 +372,17 @@ SOCCER_HD void reset4(const Consts& C, Group& S, uint32_t mask4, uint32_t w0, ui
 //   of a combination equals its second quarter threshold); `cls4` its weight class for prob_code.  Otherwise the moves
 //   are the actions and the quarter is the top two bits of each lane's random word (slip_prob == 0: list
 //   probabilities are 1, .5/.5 or .25 x 4, i.e. floor(2u) / floor(4u)).
-// w0..w3: the lanes' random words (u = (w >> 2) * 2^-30, reset draw = w & 3).
+// R: the lanes' random bits of this tick (Rand4); with SLIP its kq is the quarter from slip_select4, k4 << 6.
+// TRUSTED: the action bytes were produced by the kernel itself (sampled in 0..4): no canonical form, no misuse report.
 // GEO: 0 the pitch geometry by arithmetic (any pitch that fits), 1 by byte tables (Consts::small).
-template <bool GENERAL, bool FULL, bool SLIP, int GEO = 0>
-SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw, uint32_t sa, uint32_t sb, uint32_t k4,
-                     uint32_t cls4, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, Out& o) {
+template <bool GENERAL, bool FULL, bool SLIP, int GEO = 0, bool TRUSTED = false>
+SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw, uint32_t sa, uint32_t sb,
+                     uint32_t cls4, const Rand4& R, Out& o) {
     const uint32_t ra = S.ra, ca = S.ca, rb = S.rb, cb = S.cb, ps = S.ps, t = S.tt;
     // ---- actions: the low three bits select the move, 5..7 are NOOP; any byte outside 0..4 is reported ---------------
-    uint32_t aa = canon4(aa_raw), ab = canon4(ab_raw);
-    o.bad_action = (aa ^ aa_raw) | (ab ^ ab_raw);
+    uint32_t aa = aa_raw, ab = ab_raw;
+    if (TRUSTED) o.bad_action = 0u;
+    else { aa = canon4(aa_raw); ab = canon4(ab_raw); o.bad_action = (aa ^ aa_raw) | (ab ^ ab_raw); }
     const uint32_t p7 = ps << 7;                                           // flag: B has the ball
     const uint32_t pm = mask_of(p7);
     uint32_t frz7 = 0u, hold_m = 0u, frz_m = 0u;
@@ -364,15 +419,8 @@ SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw
     const uint32_t mv = ~(cs | same);                                      // both move (:360)
     // ---- the outcome draw ---------------------------------------------------------------------------------------------
     // kb1 / kb0: flag words of bit 1 / bit 0 of the outcome index k (coin lists use k = bit 1 of the two-bit draw)
-    uint32_t kb1, kb0c, kb0f;                                              // kb0 for coin lists / for four-way lists
-    // the top byte (outcome draw) and the low byte (reset draw) of the four random words, packed pairwise once
-    const uint32_t x01 = perm(w1, w0, 0x04000703u), x23 = perm(w3, w2, 0x04000703u);
-    if (!SLIP) {
-        const uint32_t T4 = perm(x23, x01, 0x05040100u);                   // byte j = top byte of lane j's word
-        kb1 = T4; kb0c = T4; kb0f = T4 << 1;                               // floor(2u) / floor(4u): bits 31 and 30
-    } else {
-        kb1 = k4 << 6; kb0c = kb1; kb0f = k4 << 7;                         // quarter 0..3: bit 1 / bit 1 / bit 0
-    }
+    // quarter 0..3 of the draw: a coin list takes bit 1 (floor(2u)), a four-way list both bits (floor(4u))
+    const uint32_t kb1 = R.kq, kb0c = R.kq, kb0f = R.kq << 1;              // kb0 for coin lists / for four-way lists
     const uint32_t amv = (four & kb1) | mv;                                // A takes its cell: k >= 2 of a four-way tie
     const uint32_t bmv = bfi(kb1, mv, four | mv);                          // B takes its cell: k < 2
     const uint32_t am = mask_of(amv), bm = mask_of(bmv);
@@ -409,7 +457,7 @@ SOCCER_HD void step4(const Consts& C, Group& S, uint32_t aa_raw, uint32_t ab_raw
     uint32_t obs_zero7 = goal7;
     if (!GENERAL || C.autoreset) {                                         // wave-uniform
         const uint32_t rm = mask_of(fin7);
-        const uint32_t idx = (perm(x23, x01, 0x07060302u) >> C.isd_shift) & C.isd_mask;   // byte j = low byte of lane j's word
+        const uint32_t idx = R.rs & C.isd_mask;                            // lane j's reset draw
         fra = bfi(rm, perm(0u, C.isd_ra, idx), fra); fca = bfi(rm, C.isd_ca4, fca);
         frb = bfi(rm, perm(0u, C.isd_rb, idx), frb); fcb = bfi(rm, C.isd_cb4, fcb);
         p01 = bfi(rm, perm(0u, C.isd_p, idx), p01);

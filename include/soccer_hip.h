@@ -29,15 +29,22 @@
  * Randomness (replaces the reference's per-env np.random.RandomState,
  * :57-58, consumed once per step and once per reset through gym's
  * categorical_sample, :395, :414):
- *   every batched_reset / batched_step call consumes one "tick" of the handle.
- *   Four consecutive GLOBAL lanes share ONE Philox4x32-10 block per tick:
- *       g = lane_offset + i,  q = g >> 2
- *       key     = (seed & 0xffffffff, seed >> 32)
- *       counter = (q & 0xffffffff, q >> 32, k & 0xffffffff, (k >> 32) | purpose << 31)
- *   (purpose 0: step/reset, 1: in-kernel action sampling; k < 2^63) and lane g takes word g & 3:
- *       step uniform   u = (w >> 2) * 2^-30          (30-bit, in [0,1))
- *       reset uniform  u = (w & 3) / 4               (the ISD has 2 or 4 equiprobable entries)
- *   so results depend on (seed, global lane id, tick) only — never on the
+ *   every batched_reset / batched_step call consumes one "tick" k of the handle (a T-step rollout consumes T).
+ *   Four consecutive GLOBAL lanes share Philox4x32-10 blocks:
+ *       g = lane_offset + i,  q = g >> 2,  key = (seed & 0xffffffff, seed >> 32)
+ *       block(c, purpose) = philox4x32_10(counter = (q & 0xffffffff, q >> 32, c & 0xffffffff, (c >> 32) | purpose << 31), key)
+ *   (purpose 0: step/reset, 1: in-kernel action sampling; k < 2^63) and lane g owns word w = block[g & 3].
+ *   A uniform is always u = (m + 1/2) * 2^-b for a b-bit integer m — never 0, never on a dyadic threshold:
+ *     slip_prob > 0   one block per tick, block(k, 0):
+ *         step uniform   u = ((w >> 2) + 1/2) * 2^-30      (30 bits)
+ *         reset uniform  u = ((w & 3) + 1/2) / 4           (the ISD has 2 or 4 equiprobable entries, :146-165)
+ *     slip_prob == 0  every list probability is 1, 1/2 or 1/4 (:326-360), so a step needs floor(4u) and nothing else:
+ *       ONE block serves EIGHT ticks, block(k >> 3, 0); tick k takes nibble number (k & 7) ^ 1 of w, counted from the
+ *       least significant end:   nib = (w >> (4 * ((k & 7) ^ 1))) & 15
+ *         step uniform   u = ((nib >> 2) + 1/2) / 4
+ *         reset uniform  u = ((nib & 3) + 1/2) / 4
+ *       (ABI 3.  The fused rollout is bound by vector issue, and a Philox block per step was a third of it.)
+ *   So results depend on (seed, global lane id, tick) only — never on the
  *   device count or the launch geometry.  Callers that want to feed their own
  *   uniforms (e.g. the single-env facade, which keeps the reference's MT19937
  *   stream on the host) pass u_step / u_reset arrays instead.
@@ -54,7 +61,8 @@
 extern "C" {
 #endif
 
-#define SOCCER_ABI_VERSION 2      /* 2: soccer_step_args grew reward_a_f32 / reward_b_f32 / finished */
+#define SOCCER_ABI_VERSION 3      /* 2: soccer_step_args grew reward_a_f32 / reward_b_f32 / finished
+                                     3: the bits -> uniform convention above (half-step offset; eight ticks per block at slip_prob == 0) */
 
 /* error codes */
 #define SOCCER_OK            0

@@ -292,18 +292,34 @@ void soc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* The product's per-lane randomness (include/soccer_hip.h): one Philox block per four consecutive
- * global lanes, q = g >> 2, counter = (q_lo, q_hi, tick_lo, tick_hi | purpose << 31); lane g uses
- * word g & 3:  step uniform = (w >> 2) * 2^-30,  reset uniform = (w & 3) / 4. */
-static uint32_t lane_word(uint64_t seed, uint64_t g, uint64_t tick, uint32_t purpose) {
+/* The product's per-lane randomness (include/soccer_hip.h, ABI 3): four consecutive global lanes share Philox blocks,
+ * q = g >> 2, counter = (q_lo, q_hi, c_lo, c_hi | purpose << 31); lane g owns word g & 3.  Every uniform is
+ * (m + 1/2) * 2^-b.
+ *   slip_prob > 0 : block c = tick;       step m = w >> 2 (b = 30), reset m = w & 3 (b = 2)
+ *   slip_prob == 0: block c = tick >> 3;  nib = (w >> (4 * ((tick & 7) ^ 1))) & 15;  step m = nib >> 2, reset m = nib & 3 (b = 2)
+ * Sampled actions (purpose 1) always use the tick's own block. */
+static uint32_t lane_word(uint64_t seed, uint64_t g, uint64_t c, uint32_t purpose) {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint64_t q = g >> 2;
-    uint32_t ctr[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32) | (purpose << 31)};
+    uint32_t ctr[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)c, (uint32_t)(c >> 32) | (purpose << 31)};
     uint32_t w[4]; soc_philox4x32_10(ctr, key, w);
     return w[g & 3];
 }
-static double u_step_of(uint32_t w) { return (double)(w >> 2) * (1.0 / 1073741824.0); }
-static double u_reset_of(uint32_t w) { return (double)(w & 3u) * 0.25; }
+typedef struct { double u_step, u_reset; } lane_draw;
+static lane_draw draw_of(const soc_oracle* o, uint64_t seed, uint64_t g, uint64_t tick) {
+    lane_draw d;
+    if (o->slip != 0.0) {
+        uint32_t w = lane_word(seed, g, tick, 0);
+        d.u_step = ((double)(w >> 2) + 0.5) * (1.0 / 1073741824.0);
+        d.u_reset = ((double)(w & 3u) + 0.5) * 0.25;
+    } else {
+        uint32_t w = lane_word(seed, g, tick >> 3, 0);
+        uint32_t nib = (w >> (4u * (((uint32_t)tick & 7u) ^ 1u))) & 15u;
+        d.u_step = ((double)(nib >> 2) + 0.5) * 0.25;
+        d.u_reset = ((double)(nib & 3u) + 0.5) * 0.25;
+    }
+    return d;
+}
 
 /* ---- batched semantics of the product (include/soccer_hip.h), lane by lane ------------------ */
 typedef struct {
@@ -328,7 +344,7 @@ int soc_oracle_batched_reset(const soc_oracle* o, int64_t n, soc_state* s, const
                              uint64_t tick, uint16_t* obs) {
     for (int64_t i = 0; i < n; ++i) {
         if (!mask || mask[i]) {
-            double u = u_reset ? u_reset[i] : u_reset_of(lane_word(seed, lane_offset + (uint64_t)i, tick, 0));
+            double u = u_reset ? u_reset[i] : draw_of(o, seed, lane_offset + (uint64_t)i, tick).u_reset;
             do_reset_lane(o, s, i, u);
         }
         if (obs) {
@@ -364,9 +380,9 @@ int64_t soc_oracle_batched_step(const soc_oracle* o, int64_t n, soc_state* s,
             if (prob_code) prob_code[i] = 0;
             continue;
         }
-        uint32_t w = 0;
-        if (!u_step || (autoreset && !u_reset)) w = lane_word(seed, lane_offset + (uint64_t)i, tick, 0);
-        double u = u_step ? u_step[i] : u_step_of(w);
+        lane_draw dr = {0.0, 0.0};
+        if (!u_step || (autoreset && !u_reset)) dr = draw_of(o, seed, lane_offset + (uint64_t)i, tick);
+        double u = u_step ? u_step[i] : dr.u_step;
         const trans_list* tl = &o->P[(size_t)f * 25 + act_a[i] * 5 + act_b[i]];   /* :394 */
         int k = categorical_sample(tl->p, tl->n, u);                              /* :395 */
         int32_t ns = tl->ns[k];                                                   /* :396 */
@@ -391,7 +407,7 @@ int64_t soc_oracle_batched_step(const soc_oracle* o, int64_t n, soc_state* s,
         }
         if (need && hist) hist[tl->r[k] + 1] += 1;
         if (need && autoreset) {
-            double ur = u_reset ? u_reset[i] : u_reset_of(w);
+            double ur = u_reset ? u_reset[i] : dr.u_reset;
             do_reset_lane(o, s, i, ur);
             int32_t f2 = flat(o, s->row_a[i], s->col_a[i], s->row_b[i], s->col_b[i], s->poss[i] & 1);
             ob = obs_of(o, f2);

@@ -18,7 +18,9 @@ static void st4(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
 // slip_prob > 0: the combination and the quarter are selected from the words by swar::slip_select4 with the tables of
 // soccer_slip.hpp (what soccer_create builds).
 // Returns 0, -1 when the pitch does not qualify for the byte-parallel path, -3 when the slip does not.
-// danger[n / 4]: groups that drew one of the handle's dangerous integers (slip_int == 2), see below.
+// The words are taken the one-word-per-lane-and-tick way (swar::rand_words: quarter draw = the two top bits, reset draw =
+// the two low bits) at every slip_prob, so the rules are exercised with every draw independently of the RNG convention;
+// swar_draws_host below checks the eight-ticks-per-block extraction of slip_prob == 0 handles.
 static int geo = -1;     // -1: as the library (tables on small pitches); 0: force the arithmetic geometry
 extern "C" void swar_set_geo(int g) { geo = g; }
 
@@ -26,7 +28,7 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
                               uint8_t* ra, uint8_t* ca, uint8_t* rb, uint8_t* cb, uint8_t* ps, uint8_t* tt,
                               const uint8_t* act_a, const uint8_t* act_b, const uint32_t* words, double slip_prob,
                               uint16_t* obs, uint16_t* final_obs, uint8_t* rew, uint8_t* term, uint8_t* trunc,
-                              uint8_t* code, uint8_t* finished, uint8_t* frozen, uint8_t* bad, uint8_t* danger) {
+                              uint8_t* code, uint8_t* finished, uint8_t* frozen, uint8_t* bad) {
     Rules R;
     if (!R.build(width, height).empty()) return -2;
     if (!swar::fits(R.H, R.W, max_steps)) return -1;
@@ -46,9 +48,11 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
         const uint32_t* w = words + i;
         uint32_t s_a = 0u, s_b = 0u, k4 = 0u, c4 = 0u;
         if (slip) swar::slip_select4(L, ST.sub, swar::canon4(a), swar::canon4(b), w[0], w[1], w[2], w[3], s_a, s_b, k4, c4);
+        swar::Rand4 rnd = swar::rand_words(C.isd_shift, w[0], w[1], w[2], w[3]);
+        if (slip) rnd.kq = k4 << 6;
         // geometry: byte tables where the pitch allows (what the library picks), arithmetic otherwise or when geo == 0 is forced
-#define CALL(G, F, SL) do { if (C.small && geo != 0) swar::step4<G, F, SL, 1>(C, S, a, b, s_a, s_b, k4, c4, w[0], w[1], w[2], w[3], o); \
-                            else swar::step4<G, F, SL, 0>(C, S, a, b, s_a, s_b, k4, c4, w[0], w[1], w[2], w[3], o); } while (0)
+#define CALL(G, F, SL) do { if (C.small && geo != 0) swar::step4<G, F, SL, 1>(C, S, a, b, s_a, s_b, c4, rnd, o); \
+                            else swar::step4<G, F, SL, 0>(C, S, a, b, s_a, s_b, c4, rnd, o); } while (0)
         if (slip) { if (general) { if (full) CALL(true, true, true); else CALL(true, false, true); }
                     else { if (full) CALL(false, true, true); else CALL(false, false, true); } }
         else { if (general) { if (full) CALL(true, true, false); else CALL(true, false, false); }
@@ -64,11 +68,6 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
         st4(rew + i, o.rew); st4(term + i, o.term); st4(trunc + i, o.trunc);
         st4(finished + i, (o.finished >> 7) & 0x01010101u); st4(frozen + i, (o.frozen >> 7) & 0x01010101u);
         bad[i >> 2] = o.bad_action != 0u;
-        // slip_int == 2: a group one of whose lanes drew a dangerous integer leaves the byte-parallel path in the kernels
-        // (slow_group4: float64 walk); here it is only reported, the caller leaves it out of the comparison
-        uint8_t hit = 0;
-        if (slip) for (int q = 0; q < 4; ++q) for (int j = 0; j < 4; ++j) hit |= (w[j] >> 2) == ST.danger[q];
-        danger[i >> 2] = hit;
     }
     return 0;
 }
@@ -84,10 +83,38 @@ extern "C" int swar_reset_host(int width, int height, long n, uint8_t* ra, uint8
         swar::Group S{ld4(ra + i), ld4(ca + i), ld4(rb + i), ld4(cb + i), ld4(ps + i), ld4(tt + i)};
         uint32_t lo, hi;
         const uint32_t* w = words + i;
-        if (mask) swar::reset4<true>(C, S, ld4(mask + i), w[0], w[1], w[2], w[3], lo, hi);
-        else swar::reset4<false>(C, S, 0u, w[0], w[1], w[2], w[3], lo, hi);
+        const swar::Rand4 rnd = swar::rand_words(C.isd_shift, w[0], w[1], w[2], w[3]);
+        if (mask) swar::reset4<true>(C, S, ld4(mask + i), rnd, lo, hi);
+        else swar::reset4<false>(C, S, 0u, rnd, lo, hi);
         st4(ra + i, S.ra); st4(ca + i, S.ca); st4(rb + i, S.rb); st4(cb + i, S.cb); st4(ps + i, S.ps); st4(tt + i, S.tt);
         obs[i] = (uint16_t)lo; obs[i + 1] = (uint16_t)(lo >> 16); obs[i + 2] = (uint16_t)hi; obs[i + 3] = (uint16_t)(hi >> 16);
     }
     return 0;
+}
+
+// The draws of slip_prob == 0 handles (include/soccer_hip.h, ABI 3): one block (four words, one per lane of the group)
+// serves eight ticks.  For every tick t = 0..7 this reports what the kernels extract, both ways they do it:
+//   out[(t * 2 + 0) * 4 + j] = quarter draw | reset draw << 4 of lane j by swar::rand_nibble (single steps, resets)
+//   out[(t * 2 + 1) * 4 + j] = the same by swar::transpose4 + swar::rand_pair with the rotation the rollout loop applies
+// isd_shift = 0: the reset draw is reported as the full two bits.
+extern "C" void swar_draws_host(const uint32_t* w, uint8_t* out) {
+    uint32_t p0, p1, p2, p3;
+    swar::transpose4(w[0], w[1], w[2], w[3], p0, p1, p2, p3);
+    for (uint32_t t = 0; t < 8; ++t) {
+        const swar::Rand4 a = swar::rand_nibble(0u, t, w[0], w[1], w[2], w[3]);
+        const swar::Rand4 b = swar::rand_pair(0u, t, p0);
+        if (t & 1u) { p0 = p1; p1 = p2; p2 = p3; }
+        for (int j = 0; j < 4; ++j) {
+            out[(t * 2 + 0) * 4 + j] = (uint8_t)(((a.kq >> (8 * j + 6)) & 3u) | (((a.rs >> (8 * j)) & 3u) << 4));
+            out[(t * 2 + 1) * 4 + j] = (uint8_t)(((b.kq >> (8 * j + 6)) & 3u) | (((b.rs >> (8 * j)) & 3u) << 4));
+        }
+    }
+}
+
+// what soccer_create derives from slip_prob (soccer_slip.hpp), for the CPU test of the integer slip decision
+extern "C" void swar_slip_tables(double slip_prob, uint32_t* cb9, uint32_t* sub36, uint32_t* flags, double* w4) {
+    const SlipTables T = build_slip_tables(slip_prob);
+    for (int i = 0; i < 9; ++i) { cb9[i] = T.CB[i]; sub36[4 * i] = T.sub[i].x; sub36[4 * i + 1] = T.sub[i].y; sub36[4 * i + 2] = T.sub[i].z; sub36[4 * i + 3] = T.sub[i].w; }
+    flags[0] = T.slip_int; flags[1] = T.swar_ok ? 1u : 0u; flags[2] = T.nb; flags[3] = T.c_off;
+    for (int i = 0; i < 4; ++i) w4[i] = T.w[i];
 }

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libsoccer_hip.so does not export %s" % name
     assert sorted(_lib.PROTOTYPES) == declared, "ctypes prototypes and header disagree"
-    assert lib.soccer_abi_version() == 2
+    assert lib.soccer_abi_version() == 3
 
 
 def test_struct_layouts_match_header(tmp_path):

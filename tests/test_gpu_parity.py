@@ -330,10 +330,12 @@ def _outcomes_per_combination(o_tab, st, aa, ab, slip):
 
 
 def test_philox_draws_on_slip_thresholds_match_the_float64_cumsum():
-    """The slip kernels decide u >= threshold on integers for Philox draws (u = m * 2^-30).  Replay draws whose
-    m sits exactly ON a scaled threshold or one below it (found by tools/find_threshold_draws.py in the handle's
+    """The slip kernels decide "running sum <= u" on integers for Philox draws (u = (m + 1/2) * 2^-30: m >= c).  Replay
+    draws whose m sits ON an integer threshold c or next to it (found by tools/find_threshold_draws.py in the handle's
     own Philox stream) from states where that threshold separates two outcomes; the oracle walks the float64
-    running sum like categorical_sample.  Both the step and the rollout kernels."""
+    running sum like categorical_sample.  Both the step and the rollout kernels.  Includes slip 0.1's draws on its
+    mathematically dyadic threshold 27/32 and slips 0.15 / 0.4 / 2/3, whose list shapes round differently at such a
+    threshold — all of them plain integer handles since ABI 3 (csrc/soccer_slip.hpp)."""
     import json
     d = json.load(open(os.path.join(GOLDEN, "threshold_draws.json")))
     seed = d["seed"]
@@ -382,7 +384,7 @@ def test_philox_draws_on_slip_thresholds_match_the_float64_cumsum():
             kinds.add(name)
         b.close()
     assert checked > 300 and kinds == {"end", "two", "four1", "four2", "four3"}
-    assert any(h.get("danger") for h in d["hits"])      # slip 0.1: draws exactly on its near-integer threshold (float64 fallback lane)
+    assert any(h["slip"] == 0.1 and h["m"] == 27 * 2 ** 25 for h in d["hits"])      # slip 0.1: draws exactly on 27/32
 
 
 @pytest.mark.parametrize("learner", ["player_a", "player_b"])

@@ -23,7 +23,9 @@ def host(tmp_path_factory):
                            os.path.join(ROOT, "tests", "host", "swar_host.cpp")])
     L = C.CDLL(so)
     L.swar_step_host.restype = C.c_int
-    L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 10
+    L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 9
+    L.swar_draws_host.argtypes = [C.c_void_p, C.c_void_p]
+    L.swar_slip_tables.argtypes = [C.c_double] + [C.c_void_p] * 4
     L.swar_reset_host.restype = C.c_int
     L.swar_reset_host.argtypes = [C.c_int, C.c_int, C.c_long] + [C.c_void_p] * 9
     return L
@@ -48,15 +50,13 @@ def _run_swar(L, w, h, max_steps, autoreset, general, full, st, t, need, aa, ab,
     tt = np.ascontiguousarray(t, np.uint8)
     out = dict(obs=np.zeros(n, np.uint16), final_obs=np.zeros(n, np.uint16), reward=np.zeros(n, np.uint8),
                terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), prob_code=np.zeros(n, np.uint8),
-               finished=np.zeros(n, np.uint8), frozen=np.zeros(n, np.uint8), bad=np.zeros(n // 4, np.uint8),
-               danger=np.zeros(n // 4, np.uint8))
+               finished=np.zeros(n, np.uint8), frozen=np.zeros(n, np.uint8), bad=np.zeros(n // 4, np.uint8))
     rc = L.swar_step_host(w, h, max_steps, int(autoreset), int(general), int(full), n,
                           _p(ra), _p(ca), _p(rb), _p(cb), _p(ps), _p(tt),
                           _p(np.ascontiguousarray(aa, np.uint8)), _p(np.ascontiguousarray(ab, np.uint8)),
                           _p(np.ascontiguousarray(words, np.uint32)), float(slip),
                           _p(out["obs"]), _p(out["final_obs"]), _p(out["reward"]), _p(out["terminated"]),
-                          _p(out["truncated"]), _p(out["prob_code"]), _p(out["finished"]), _p(out["frozen"]), _p(out["bad"]),
-                          _p(out["danger"]))
+                          _p(out["truncated"]), _p(out["prob_code"]), _p(out["finished"]), _p(out["frozen"]), _p(out["bad"]))
     assert rc == 0
     out["reward"] = out["reward"].view(np.int8)
     out["state"] = (ra, ca, rb, cb, ps, tt)
@@ -88,17 +88,13 @@ def _oracle_step(w, h, max_steps, autoreset, st, t, need, aa, ab, words, slip=0.
     n = len(t)
     o = Oracle(w, h, slip, n=n, autoreset=autoreset, max_steps=max_steps)
     o.set_state(st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], t=t, needs_reset=need)
-    c = o.step(aa, ab, u_step=(words >> 2).astype(np.float64) * 2.0 ** -30, u_reset=(words & 3).astype(np.float64) * 0.25)
+    # the uniforms of one word per lane (include/soccer_hip.h): u = (m + 1/2) * 2^-b
+    c = o.step(aa, ab, u_step=((words >> 2).astype(np.float64) + 0.5) * 2.0 ** -30, u_reset=((words & 3).astype(np.float64) + 0.5) * 0.25)
     c["state"] = (o.row_a.view(np.uint8), o.col_a.view(np.uint8), o.row_b.view(np.uint8), o.col_b.view(np.uint8), o.poss, o.t)
     return c
 
 
 def _compare(got, exp, need, full):
-    keep = np.repeat(got["danger"] == 0, 4)        # groups with a dangerous draw leave the byte-parallel path in the kernels
-    if not keep.all():
-        got = {k: (tuple(x[keep] for x in v) if k == "state" else v[keep] if len(v) == len(keep) else v) for k, v in got.items()}
-        exp = {k: (tuple(x[keep] for x in v) if k == "state" else v[keep] if hasattr(v, "__len__") and len(v) == len(keep) else v) for k, v in exp.items()}
-        need = need[keep]
     for k in ("obs", "reward", "terminated", "truncated") + (("final_obs", "prob_code") if full else ()):
         bad = np.flatnonzero(got[k] != exp[k])
         assert bad.size == 0, "%s differs on %d lanes, first %d: got %s expected %s" % (k, bad.size, bad[0], got[k][bad[0]], exp[k][bad[0]])
@@ -210,7 +206,7 @@ def _slip_words(slip, n, rng):
         for q in (0.25, 0.5, 0.75, 1.0):
             edges.append(acc + wgt * q)
         acc += wgt
-    m_edge = np.array([int(np.ceil(e * 2 ** 30)) for e in edges if e < 1.0], dtype=np.int64)
+    m_edge = np.array([int(np.ceil(e * 2 ** 30 - 0.5)) for e in edges if e < 1.0], dtype=np.int64)
     special = np.concatenate([m_edge - 1, m_edge, m_edge + 1, [0, 1, 2 ** 30 - 1]])
     special = special[(special >= 0) & (special < 2 ** 30)]
     m = rng.integers(0, 1 << 30, size=n, dtype=np.int64)
@@ -220,7 +216,7 @@ def _slip_words(slip, n, rng):
 
 
 @pytest.mark.parametrize("w,h,slip", [(5, 4, 0.2), (5, 4, 0.5), (5, 4, 1.0), (5, 4, 0.3), (5, 4, 0.05), (7, 5, 0.3), (11, 7, 0.2),
-                                      (5, 4, 0.1), (5, 4, 0.9), (5, 4, 0.15), (6, 4, 0.4)])
+                                      (5, 4, 0.1), (5, 4, 0.9), (5, 4, 0.15), (6, 4, 0.4), (5, 4, 2.0 / 3.0), (5, 4, 0.6)])
 def test_slip_step_every_tuple_and_action_with_draws_on_every_threshold(host, w, h, slip):
     rng = np.random.default_rng(int(slip * 100) + w)
     o = Oracle(w, h, slip, n=1)
@@ -248,18 +244,60 @@ def test_slip_step_every_tuple_and_action_with_draws_on_every_threshold(host, w,
     _compare(got, exp, need0, False)
 
 
-def test_dangerous_draws_are_reported_per_group(host):
-    """0.1 / 0.9 have one scaled threshold within 2^-10 of an integer (slip_int == 2): the kernels send a thread that drew
-    exactly that integer through the float64 walk (tests/test_gpu_parity.py replays such draws on the GPU); the host
-    harness reports those groups so that the comparisons above leave them out — and only them."""
-    n = 64
-    st = np.tile(np.array([[1, 2, 2, 4, 0]]), (n, 1)); z = np.zeros(n, np.int64)
-    m_danger = int(round((0.81 + 3 * 0.01125) * 2 ** 30))          # 0.84375 * 2^30, exactly an integer
-    words = np.full(n, 12345 << 2, np.uint32); words[5] = m_danger << 2; words[40] = (m_danger << 2) | 3
-    got = _run_swar(host, 5, 4, 100, True, True, False, st, z, z, z, z, words, slip=0.1)
-    assert np.flatnonzero(got["danger"]).tolist() == [1, 10]
-    got = _run_swar(host, 5, 4, 100, True, True, False, st, z, z, z, z, words, slip=0.2)
-    assert not got["danger"].any()
+SLIPS = [0.05, 0.1, 0.15, 0.2, 0.25, 0.3, 1.0 / 3.0, 0.33, 0.4, 0.5, 0.6, 2.0 / 3.0, 0.75, 0.9, 0.999, 1.0, 1e-9, 0.123]
+
+
+@pytest.mark.parametrize("slip", SLIPS)
+def test_integer_slip_thresholds_are_the_float64_cumsum_for_every_list_shape(host, slip):
+    """soccer_slip.hpp accepts the integer slip decision only when, at every entry position, c = ceil(t * 2^30 - 1/2) is the
+    same for the running sum t of EVERY list shape.  Checked here independently: random shapes (each combination
+    contributing 1, 2 or 4 entries), the running sums by np.cumsum — the reference's own categorical_sample arithmetic —
+    and c with exact rational arithmetic.  Decimal slips such as 0.1 / 0.15 / 0.4 / 2/3, whose mathematically dyadic
+    thresholds needed a float64 walk inside the kernels under round 2's u = m * 2^-30, are plain integer handles now."""
+    from fractions import Fraction
+    import math
+    cb = np.zeros(9, np.uint32); sub = np.zeros(36, np.uint32); flags = np.zeros(4, np.uint32); w4 = np.zeros(4, np.float64)
+    host.swar_slip_tables(float(slip), _p(cb), _p(sub), _p(flags), _p(w4))
+    assert flags[0] == 1 and flags[1] == 1, "slip %r should take the integer decision on the byte-parallel path" % slip
+    s = slip
+    c = [(1 - s) * (1 - s), (1 - s) * s * 0.5, (1 - s) * s * 0.5, s * (1 - s) * 0.5, s * (1 - s) * 0.5] + [s * s * 0.25] * 4   # :209-223
+    np.testing.assert_array_equal(w4, [c[0], c[1], c[3], c[5]])
+    active = [x for x in c if x != 0.0]                                # :226-227
+    assert len(active) == flags[2]
+    rng = np.random.default_rng(int(slip * 1e6) % 9973)
+    def c_of(t):
+        return min(max(math.ceil(Fraction(float(t)) * 2 ** 30 - Fraction(1, 2)), 0), 2 ** 30)
+    for _ in range(400):
+        shape = rng.choice([1, 2, 4], size=len(active))
+        plist = [wgt * {1: 1.0, 2: 0.5, 4: 0.25}[int(n)] for wgt, n in zip(active, shape) for _k in range(int(n))]   # :241
+        run = np.cumsum(np.asarray(plist))                             # gym's categorical_sample: cumsum(asarray(p)) > u
+        pos = 0
+        for i, n in enumerate(shape):
+            ends = [c_of(t) for t in run[pos:pos + n]]
+            pos += n
+            assert ends[-1] == cb[i]
+            if n == 2:
+                assert ends[0] == sub[4 * i] == sub[4 * i + 2]
+            if n == 4:
+                assert ends[:3] == [int(x) for x in sub[4 * i + 1:4 * i + 4]]
+    assert cb[len(active) - 1] == 2 ** 30                              # no draw falls beyond the last entry
+
+
+def test_eight_ticks_share_one_block_at_slip_zero(host):
+    """slip_prob == 0 (include/soccer_hip.h, ABI 3): tick k takes nibble (k & 7) ^ 1 of the lane's word of block k >> 3;
+    quarter draw = the nibble's two high bits, reset draw = its two low bits.  Both extraction forms of the kernels
+    (rotate + pack for single steps, transposed block + pair walk for the rollout) against that definition."""
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        w = rng.integers(0, 1 << 32, size=4, dtype=np.uint64).astype(np.uint32)
+        out = np.zeros(64, np.uint8)
+        host.swar_draws_host(_p(w), _p(out))
+        out = out.reshape(8, 2, 4)
+        for t in range(8):
+            nib = (w >> np.uint32(4 * (t ^ 1))) & np.uint32(15)
+            exp = (nib >> 2) | ((nib & 3) << 4)
+            np.testing.assert_array_equal(out[t, 0], exp)
+            np.testing.assert_array_equal(out[t, 1], exp)
 
 
 @pytest.mark.parametrize("w,h", PITCHES)
@@ -279,7 +317,7 @@ def test_reset_all_lanes_and_masked(host, w, h):
     for mask in (None, np.array([0, 1, 255, 128, 0, 0, 2, 0], np.uint8)[rng.integers(0, 8, size=n)]):
         oo = Oracle(w, h, 0.0, n=n)
         oo.set_state(st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], t=t, needs_reset=need)
-        exp = oo.reset(mask=mask, u_reset=(words & 3).astype(np.float64) * 0.25)
+        exp = oo.reset(mask=mask, u_reset=((words & 3).astype(np.float64) + 0.5) * 0.25)
         ra, ca, rb, cb = (np.ascontiguousarray(st[:, k], np.uint8) for k in range(4))
         ps = np.ascontiguousarray(st[:, 4] | (need << 1), np.uint8); tt = np.ascontiguousarray(t, np.uint8)
         obs = np.zeros(n, np.uint16)

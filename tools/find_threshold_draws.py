@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """Search the handle's Philox stream for draws that land ON or NEXT TO a slip threshold.
 
-A lane's step uniform is u = m * 2^-30 with m = word >> 2 (include/soccer_hip.h).  The slip kernels decide
-"u >= threshold" on integers (m >= ceil(threshold * 2^30)); this script finds (global lane, tick) pairs whose m
-equals such a scaled threshold or the integer below it, for tests/test_gpu_parity.py to replay against the
-oracle's float64 cumsum.  Pure numpy (vectorised Philox4x32-10, the spec's own definition); writes
+A lane's step uniform at slip_prob > 0 is u = (m + 1/2) * 2^-30 with m = word >> 2 (include/soccer_hip.h, ABI 3).
+The slip kernels decide "running sum <= u" on integers (m >= c, c = ceil(sum * 2^30 - 1/2)); this script finds
+(global lane, tick) pairs whose m is such a c or the integer below it, for tests/test_gpu_parity.py to replay against
+the oracle's float64 cumsum.  Pure numpy (vectorised Philox4x32-10, the spec's own definition); writes
 tests/golden/threshold_draws.json.
+
+    tools/find_threshold_draws.py                 rebuild the file for the default slips
+    tools/find_threshold_draws.py 0.15 0.4 ...    search these slips and MERGE their hits into the existing file
+
+(The entries of 0.1 / 0.2 / 0.3 / 0.5 date from ABI 2, u = m * 2^-30 and c' = ceil(sum * 2^30): m in {c' - 1, c'}.  As
+c is c' or c' - 1 they still sit on or next to a threshold — within {c - 1, c, c + 1} — including the draws exactly on
+0.1's mathematically dyadic threshold 27/32, marked "danger": the ones that needed a float64 walk in the kernels then.)
 """
 import json
 import os
@@ -53,13 +60,45 @@ def thresholds(slip):
 
 def main():
     seed, n_lanes, ticks = 20241004, 1 << 22, 96
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "threshold_draws.json")
+    slips = [float(x) for x in sys.argv[1:]]
     res = {"seed": seed, "hits": []}
-    for slip in (0.2, 0.3, 0.5, 0.1):   # 0.5: dyadic, every float64 sum exact, thresholds ARE integers after scaling;
-                                        # 0.1: one scaled threshold within 2^-10 of an integer (searched for specifically below)
+    if slips:
+        res = json.load(open(out)); assert res["seed"] == seed
+        res["hits"] = [h for h in res["hits"] if h["slip"] not in slips]
+    for slip in (slips or (0.2, 0.3, 0.5, 0.1)):
         th = thresholds(slip)
         targets = {}
         for name, c, t in th:
-            x = t * 2.0 ** 30
+            x = t * 2.0 ** 30 - 0.5
+            cb = int(np.ceil(x))
+            for m in (cb - 1, cb):
+                if 0 <= m < (1 << 30):
+                    targets.setdefault(m, []).append((name, c))
+        tarr = np.array(sorted(targets), np.uint32)
+        q = np.arange(n_lanes // 4, dtype=np.uint64)
+        found = 0
+        for tick in range(ticks):
+            w = philox_blocks(q, tick, seed)
+            m = w >> 2
+            hit = np.isin(m, tarr)
+            for j, qi in zip(*np.nonzero(hit)):
+                g = int(qi) * 4 + int(j)
+                res["hits"].append({"slip": slip, "lane": g, "tick": tick, "m": int(m[j, qi]),
+                                    "thresholds": [list(x) for x in targets[int(m[j, qi])]]})
+                found += 1
+        print("slip %.2f: %d draws on/next to a threshold in %d lanes x %d ticks" % (slip, found, n_lanes, ticks), file=sys.stderr)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "threshold_draws.json")
+    slips = [float(x) for x in sys.argv[1:]]
+    res = {"seed": seed, "hits": []}
+    if slips:
+        res = json.load(open(out)); assert res["seed"] == seed
+        res["hits"] = [h for h in res["hits"] if h["slip"] not in slips]
+    for slip in (slips or (0.2, 0.3, 0.5, 0.1)):
+        th = thresholds(slip)
+        targets = {}
+        for name, c, t in th:
+            x = t * 2.0 ** 30 - 0.5
             cb = int(np.ceil(x))
             for m in (cb - 1, cb):
                 if 0 <= m < (1 << 30):
@@ -96,7 +135,6 @@ def main():
                 if got >= 3:
                     break
             print("slip %.2f: %d draws exactly on the dangerous integer(s) %s" % (slip, got, sorted(danger)), file=sys.stderr)
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "threshold_draws.json")
     with open(out, "w") as f:
         json.dump(res, f, indent=0)
     print("wrote", os.path.normpath(out), len(res["hits"]), "hits")
