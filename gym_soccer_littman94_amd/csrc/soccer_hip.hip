@@ -537,7 +537,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
             RolloutSwar RS{P.state, P.state_stride, P.first, P.n, P.lane_offset, P.tick_in, P.tick_out, P.hist, P.misuse,
                            P.policy_a, P.policy_b, P.key0, P.key1,
-                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.hist_mask, R0.nS, 0};
+                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.hist_mask, R0.nS, 0, 0u};
             size_t smem = 36 * sizeof(uint32_t);
             const bool fixed = P.policy_a || P.policy_b;
             // both sides sampled from mixed-policy tables whose 16-byte rows fit LDS: the shape of config 5
@@ -547,6 +547,11 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             else if (dyn && (io.mix_a || io.mix_b || fixed)) {
                 const size_t need = smem + 2 * (size_t)R0.nS * sizeof(uint2) + 2 * (((size_t)R0.nS + 15) & ~size_t(15));
                 if (need <= 64 * 1024) { RS.lds_tables = 1; smem = need; }
+            }
+            if (!io.sample_actions) {        // action streams are staged through LDS: 16 dwords per thread
+                smem = (smem + 15) & ~size_t(15);
+                RS.act_off = (uint32_t)(smem / sizeof(uint32_t));
+                smem += 16 * kBlock * sizeof(uint32_t);
             }
             const uint64_t groups = P.n >> 2;
             uint64_t blocks = (groups + kBlock - 1) / kBlock;

@@ -1328,21 +1328,24 @@ struct RolloutSwar {       // everything the kernel needs, and nothing else (Ker
     swar::Consts C; swar::SlipConsts L; const swar::Quad* sub;
     uint32_t hist_mask;
     int32_t nS; int32_t lds_tables;
+    uint32_t act_off;                       // dword offset of the action staging area in dynamic LDS (16 x 256 dwords per workgroup)
 };
 
-// number of a mixed-policy row's four 16-bit cumulative thresholds (values 0..2^15) that are <= a 15-bit draw h.  `hs`
-// holds h in both halves with bit 15 set: (h + 0x8000) - t has bit 15 set exactly when h >= t, two thresholds per
-// packed subtraction, one population count for the four of them.
-__device__ __forceinline__ uint32_t count_le15(uint32_t hs, uint32_t tx, uint32_t ty) {
+// A mixed-policy row holds four 16-bit cumulative thresholds t0 <= t1 <= t2 <= t3 (values 0..2^15) as two dwords; the
+// action is the number of them that are <= the player's 15-bit draw h.  With `hs` = h in both halves and bit 15 set,
+// (h + 0x8000) - t has bit 15 set exactly when h >= t: two packed subtractions put the four answers into the sign bits
+// of bytes 1, 3, 5, 7 of an 8-byte pair, which is what v_perm_b32's selectors 8..11 replicate — one permute turns them
+// into four 0xff / 0x00 bytes and one population count gives 8 x the action.
+__device__ __forceinline__ uint32_t count8_le15(uint32_t hs, uint32_t tx, uint32_t ty) {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, tx));
     const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hs) - __builtin_bit_cast(u16x2, ty));
-    return (uint32_t)__builtin_popcount((x & 0x80008000u) | ((y >> 1) & 0x40004000u));
+    return (uint32_t)__builtin_popcount(swar::perm(y, x, 0x0b0a0908u));
 }
-// the two 15-bit action draws of a lane's purpose-1 word (da = w & 0x7fff, db = (w >> 16) & 0x7fff), each duplicated
-// into both halves with bit 15 forced: one byte permute + one OR per player
-__device__ __forceinline__ uint32_t draw_a15(uint32_t w) { return swar::perm(0u, w, 0x01000100u) | 0x80008000u; }
-__device__ __forceinline__ uint32_t draw_b15(uint32_t w) { return swar::perm(0u, w, 0x03020302u) | 0x80008000u; }
+// the two 15-bit action draws of a lane's purpose-1 word w (da = w & 0x7fff, db = (w >> 16) & 0x7fff): `wm` = w with
+// bits 15 and 31 forced, each half then duplicated by one byte permute
+__device__ __forceinline__ uint32_t draw_a15(uint32_t wm) { return swar::perm(0u, wm, 0x01000100u); }
+__device__ __forceinline__ uint32_t draw_b15(uint32_t wm) { return swar::perm(0u, wm, 0x03020302u); }
 
 // the T steps of one thread's four lanes.  GENERAL = false: no lane is frozen or in a goal tuple on entry and the handle
 // auto-resets, so none ever will be (the steady state): the step's code for those cases is compiled out.
@@ -1358,10 +1361,15 @@ __device__ __forceinline__ uint32_t draw_b15(uint32_t w) { return swar::perm(0u,
 template <int DYNM, bool SLIP, bool GENERAL, int GEO>
 __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const swar::Quad* sub,
                                                    const uint2* mix_a_in, const uint2* mix_b_in, const int8_t* pol_a_in, const int8_t* pol_b_in,
+                                                   uint32_t* act_lds,
                                                    unsigned long long i0, unsigned long long tick0, swar::Group& S,
                                                    uint32_t& fin_tot, uint32_t& nz_tot, uint32_t& neg_tot,
                                                    uint32_t (&acc)[4], uint32_t& frozen_any, uint32_t& bad_any) {
     constexpr bool DYN = DYNM != 0;
+#ifndef SOCCER_ROLLOUT_STAGED
+#define SOCCER_ROLLOUT_STAGED 1         // 0: lab builds only (tools/lib_ab.sh): one prefetched action load per step
+#endif
+    constexpr bool STAGED = SOCCER_ROLLOUT_STAGED && (DYNM == 0 || DYNM == 4 || DYNM == 5);   // action streams staged through LDS, eight steps at a time
     constexpr bool TRUSTED = DYNM == 1 || DYNM == 2;                    // both sides sampled in 0..4 by the kernel itself
     const bool sample = DYNM == 1 || DYNM == 2 || (DYNM == 3 && IO.sample_actions);
     const uint4* mix_ab = DYNM == 2 ? reinterpret_cast<const uint4*>(mix_a_in) : nullptr;   // LDS rows { a: x, y; b: z, w }
@@ -1376,16 +1384,39 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     const bool load_b = DYNM == 0 || DYNM == 4 || (DYNM == 3 && !sample && IO.act_b != nullptr);
     const bool lane_acc = IO.return_sum != nullptr || IO.episode_count != nullptr;
     const bool by_obs = DYNM == 2 || DYNM == 4 || DYNM == 5 || (DYNM == 3 && (use_pol_a || use_pol_b || use_mix_a || use_mix_b));
+    // Action streams.  A wave's loads and stores share one completion counter and may complete out of order with
+    // respect to each other, so waiting for ONE prefetched action dword means waiting for every result store issued
+    // before it: with a load per step the wave drained its stores every step and sat out their write latency (the
+    // step took 1.5 us of which the SIMD was busy 1.1).  Instead the action dwords of eight steps — the ticks of one
+    // Philox block — are fetched a block ahead into registers, parked in the thread's sixteen private LDS dwords at
+    // the block boundary (the one wait per eight steps) and read back per step by ds_read, which counts separately.
     uint32_t aa = 0u, ab = 0u;
-    if (load_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
-    if (load_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
+    uint32_t nx[16];                                                    // STAGED: the next block's action dwords, in flight
+#pragma unroll
+    for (int k = 0; k < 16; ++k) nx[k] = 0u;
+    // issue the loads of the block whose tick-0 step is `sb` (steps outside the rollout are clamped: a harmless re-read)
+    auto fetch = [&](int sb) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int st = sb + k; st = st < 0 ? 0 : st; st = st < IO.n_steps ? st : IO.n_steps - 1;
+            if (load_a) nx[2 * k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + i0));
+            if (load_b) nx[2 * k + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + i0));
+        }
+    };
+    if (STAGED) fetch(-(int)((uint32_t)tick0 & 7u));
+    else {
+        if (load_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
+        if (load_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
+    }
     // the observation of the current tuple (goal tuples: 0), carried along when an action depends on it
     uint32_t s_lo = 0u, s_hi = 0u;
     if (by_obs) {
         const uint32_t cc0 = swar::bfi(swar::mask_of(S.ps << 7), S.cb, S.ca);
         swar::obs4<true>(R.C, S.ra, S.ca, S.rb, S.cb, S.ps & swar::K01, swar::is_zero(cc0) | swar::is_zero(cc0 ^ R.C.Wm1x4), s_lo, s_hi);
     }
+    const swar::Consts& C = R.C;
     const unsigned long long q = (R.lane_offset + i0) >> 2;
+    uint32_t fin_loc = 0u, nz_loc = 0u, neg_loc = 0u;                   // this group's finished episodes / steps with a reward / see below
     uint32_t p0 = 0u, p1 = 0u, p2 = 0u, p3 = 0u;                        // !SLIP: the current eight-tick block, transposed
     if (!SLIP) {
         const unsigned long long bt = tick0 >> 3;
@@ -1395,8 +1426,18 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     }
     for (int s = 0; s < IO.n_steps; ++s) {
         const unsigned long long tick = tick0 + (unsigned long long)s;
+        const uint32_t t = (uint32_t)tick & 7u;                         // wave-uniform, like everything that steers the blocks below
+        const bool new_block = t == 0u || s == 0;
         uint32_t naa = aa, nab = ab;
-        if (s + 1 < IO.n_steps) {                                       // prefetch the next step's actions
+        if (STAGED) {
+            if (new_block) {                                            // park this block's actions, fetch the next block's
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if ((k & 1) ? load_b : load_a) act_lds[k * kBlock] = nx[k];
+                if (s + 8 - (int)t < IO.n_steps) fetch(s + 8 - (int)t);
+            }
+            if (load_a) aa = act_lds[(2u * t) * kBlock];
+            if (load_b) ab = act_lds[(2u * t + 1u) * kBlock];
+        } else if (s + 1 < IO.n_steps) {                                // DYNM == 3: prefetch the next step's actions
             if (load_a) naa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)(s + 1) * IO.act_stride + i0));
             if (load_b) nab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)(s + 1) * IO.act_stride + i0));
         }
@@ -1413,18 +1454,21 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
                 const uint32_t ob = ((j & 2 ? s_hi : s_lo) >> (16 * (j & 1))) & 0xffffu;
                 if (DYNM == 2) {                    // both sides from their tables: one 16-byte LDS row per lane
                     const uint4 th = mix_ab[ob];
-                    a4 |= count_le15(draw_a15(aw[j]), th.x, th.y) << (8 * j);
-                    b4 |= count_le15(draw_b15(aw[j]), th.z, th.w) << (8 * j);
+                    const uint32_t wm = aw[j] | 0x80008000u;
+                    a4 |= count8_le15(draw_a15(wm), th.x, th.y) << (8 * j);      // 8 x the action; divided after the loop
+                    b4 |= count8_le15(draw_b15(wm), th.z, th.w) << (8 * j);
                 } else if (sample) {                // two actions from one 32-bit word, 15 bits each
                     const uint32_t ha = aw[j] & 0x7fffu, hb = (aw[j] >> 16) & 0x7fffu;
                     uint32_t a = (ha * 5u) >> 15, b = (hb * 5u) >> 15;          // uniform
-                    if (use_mix_a) { const uint2 th = mix_a[ob]; a = count_le15(draw_a15(aw[j]), th.x, th.y); }
-                    if (use_mix_b) { const uint2 th = mix_b[ob]; b = count_le15(draw_b15(aw[j]), th.x, th.y); }
+                    const uint32_t wm = aw[j] | 0x80008000u;
+                    if (use_mix_a) { const uint2 th = mix_a[ob]; a = count8_le15(draw_a15(wm), th.x, th.y) >> 3; }
+                    if (use_mix_b) { const uint2 th = mix_b[ob]; b = count8_le15(draw_b15(wm), th.x, th.y) >> 3; }
                     a4 |= a << (8 * j); b4 |= b << (8 * j);
                 }
                 if (use_pol_a) a4 = (a4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_a[ob] << (8 * j));
                 if (use_pol_b) b4 = (b4 & ~(0xffu << (8 * j))) | ((uint32_t)(uint8_t)pol_b[ob] << (8 * j));
             }
+            if (DYNM == 2) { a4 >>= 3; b4 >>= 3; }  // every byte held 8 x (0..4): no bit crosses a byte
         }
         swar::Out o;
         uint32_t sa = 0u, sb = 0u, cls4 = 0u;
@@ -1433,18 +1477,19 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
             uint32_t k4 = 0u;
             swar::slip_select4(R.L, sub, TRUSTED ? a4 : swar::canon4(a4), TRUSTED ? b4 : swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
-            rnd = swar::Rand4{k4 << 6, swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> R.C.isd_shift};
+            rnd = swar::Rand4{k4 << 6, swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> C.isd_shift};
         } else {
-            const uint32_t t = (uint32_t)tick & 7u;                     // wave-uniform, like everything that steers this block
             if (t == 0u && s != 0) {
                 const unsigned long long bt = tick >> 3;
                 const Philox4 b = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), R.key0, R.key1);
                 swar::transpose4(b.w[0], b.w[1], b.w[2], b.w[3], p0, p1, p2, p3);
             }
-            rnd = swar::rand_pair(R.C.isd_shift, t, p0);
-            if (t & 1u) { p0 = p1; p1 = p2; p2 = p3; }
+            rnd = swar::rand_pair(C.isd_shift, t, p0);
+            // odd tick: the pair is used up.  The empty asm keeps this a (scalar) branch around three moves; as selects it
+            // was three v_cndmask_b32 every step, each several times the cost of a move (tools/valu_rate_lab.hip).
+            if (t & 1u) { asm volatile(""); p0 = p1; p1 = p2; p2 = p3; }
         }
-        swar::step4<GENERAL, false, SLIP, GEO, TRUSTED>(R.C, S, a4, b4, sa, sb, cls4, rnd, o);
+        swar::step4<GENERAL, false, SLIP, GEO, TRUSTED>(C, S, a4, b4, sa, sb, cls4, rnd, o);
         s_lo = o.obs_lo; s_hi = o.obs_hi;
         const long long off = (long long)s * IO.out_stride + (long long)i0;
         if (IO.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
@@ -1453,8 +1498,14 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         if (IO.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(IO.terminated + off));
         if (IO.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(IO.truncated + off));
         // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends an episode
-        fin_tot += (uint32_t)__builtin_popcount(o.finished & swar::K80);
-        nz_tot += (uint32_t)__builtin_popcount(o.rew & swar::K01); neg_tot += (uint32_t)__builtin_popcount(o.rew & swar::K80);
+        fin_loc += (uint32_t)__builtin_popcount(o.finished & swar::K80);
+        if (GENERAL) { nz_loc += (uint32_t)__builtin_popcount(o.rew & swar::K01); neg_loc += (uint32_t)__builtin_popcount(o.rew & swar::K80); }
+        else {
+            // without frozen / goal-tuple lanes a step terminates exactly when it carries a reward, so the clean 0 / 1 bytes of
+            // `terminated` count the rewards and the bits of the reward bytes (0x01 / 0xff) count (+1) + 8 x (-1): two
+            // population counts without a mask
+            nz_loc += (uint32_t)__builtin_popcount(o.term); neg_loc += (uint32_t)__builtin_popcount(o.rew);
+        }
         if (lane_acc) {                                             // wave-uniform
             // reward bytes sign-extended to int16 pairs (v_perm_b32's sign selectors), finished flags to 0 / 1
             acc[0] = swar::pk_add(acc[0], swar::perm(o.rew << 8, o.rew, 0x08010a00u));
@@ -1464,8 +1515,10 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         }
         if (GENERAL) frozen_any |= o.frozen;
         if (!TRUSTED) bad_any |= o.bad_action;
-        aa = naa; ab = nab;
+        if (!STAGED) { aa = naa; ab = nab; }
     }
+    fin_tot += fin_loc; nz_tot += nz_loc;
+    neg_tot += GENERAL ? neg_loc : (neg_loc - nz_loc) / 7u;             // (pos + 8 neg) - (pos + neg) = 7 neg
 }
 
 template <int DYNM, bool SLIP, int GEO = 0>
@@ -1502,6 +1555,7 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
     if (blockIdx.x == 0 && threadIdx.x == 0) *R.tick_out = tick0 + (unsigned long long)IO.n_steps;
     const unsigned long long groups = R.n >> 2;                      // the launch covers a multiple of 4 lanes
     uint32_t frozen_any = 0u, bad_any = 0u;
+    uint32_t* act_lds = smem + R.act_off + threadIdx.x;              // this thread's sixteen dwords, kBlock apart
     for (unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; g < groups;
          g += (unsigned long long)gridDim.x * kBlock) {
         const unsigned long long i0 = R.first + (g << 2);
@@ -1515,8 +1569,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
         const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
         const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
-        if (special) rollout_swar_group<DYNM, SLIP, true, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
-        else rollout_swar_group<DYNM, SLIP, false, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        if (special) rollout_swar_group<DYNM, SLIP, true, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYNM, SLIP, false, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
         uint8_t* sw = R.state + i0;
         *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
         *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;

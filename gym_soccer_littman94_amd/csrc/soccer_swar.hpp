@@ -57,7 +57,15 @@ SOCCER_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
 #endif
 }
 // v_bfi_b32: bits of x where m is set, bits of y elsewhere
-SOCCER_HD uint32_t bfi(uint32_t m, uint32_t x, uint32_t y) { return (m & x) | (~m & y); }
+// (as v_bitop3_b32, truth table 0xca: with register operands it issues like a plain logic op, v_bfi_b32 does not —
+// tools/valu_rate_lab.hip)
+SOCCER_HD uint32_t bfi(uint32_t m, uint32_t x, uint32_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(m, x, y, 0xca);
+#else
+    return (m & x) | (~m & y);
+#endif
+}
 // v_pk_mad_u16: a * b + c on the two 16-bit halves, wrapping
 SOCCER_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -105,6 +113,7 @@ SOCCER_HD uint32_t is_zero(uint32_t x) { return K80 - x; }
 // Wave-uniform constants of a handle; built once on the host (make_consts) and passed by value.
 struct Consts {
     uint32_t Wx2;          // W | W << 16: cell id = row * W + col, two byte pairs at a time
+    uint32_t Wm2x2;        // (W - 2) in both halves: interior-cell index + 1 = row * (W - 2) + col
     uint32_t Hp1x4;        // (H + 1) in every byte
     uint32_t Wm1x4;        // (W - 1) in every byte: B's goal line (column 0 is A's)
     uint32_t gr_lo_add;    // (0x80 - goal_lo) in every byte: bit 7 of row + this  <=>  row >= goal_lo   (:60)
@@ -139,6 +148,7 @@ inline Consts make_consts(int H, int W, int goal_lo, int goal_hi, int max_steps,
     Consts C{};
     auto splat = [](uint32_t b) { return (b & 0xffu) * K01; };
     C.Wx2 = (uint32_t)W | ((uint32_t)W << 16);
+    C.Wm2x2 = (uint32_t)(W - 2) | ((uint32_t)(W - 2) << 16);
     C.Hp1x4 = splat((uint32_t)H + 1u);
     C.Wm1x4 = splat((uint32_t)W - 1u);
     C.gr_lo_add = splat(0x80u - (uint32_t)goal_lo);
@@ -324,17 +334,19 @@ SOCCER_HD void slip_select4(const SlipConsts& L, const Quad* sub, uint32_t aa, u
 }
 
 // Observation index of four tuples (ra, ca, rb, cb, p): 1 + 2 * (iA * (NI - 1) + iB - (iB > iA)) + p over interior-cell
-// indices i = row * (W - 2) + col - 1 = cell - 2 * row - 1 (Rules::build checks the table against this closed form of
-// the reference's enumeration order, :63-109), evaluated as iA * 2(NI - 1) + (2 * (iB - gt) + 1 + p) on two 16-bit
-// halves at a time.  ZERO: lanes flagged in `zero7` (goal tuples, :493-494) get index 0.
+// indices i = row * (W - 2) + col - 1 (Rules::build checks the table against this closed form of the reference's
+// enumeration order, :63-109), evaluated as iA * 2(NI - 1) + (2 * (iB - gt) + 1 + p) on two 16-bit halves at a time.
+// j = i + 1 comes straight out of one packed multiply-add per player; every byte stays within 0..255 and never borrows:
+// 2 * jB + p <= 2 * NI + 3 <= 255 (swar::fits), and jB >= 2 whenever iB > iA.  ZERO: lanes flagged in `zero7` (goal
+// tuples, :493-494) get index 0 (their bytes above are meaningless but still borrow-free: a carrier in a goal column
+// stands in a goal row >= 1, so j >= W - 2).
 template <bool ZERO>
 SOCCER_HD void obs4(const Consts& C, uint32_t r_a, uint32_t c_a, uint32_t r_b, uint32_t c_b, uint32_t p01, uint32_t zero7,
                     uint32_t& lo, uint32_t& hi) {
-    const uint32_t cA = pk_mad(r_a, C.Wx2, c_a), cB = pk_mad(r_b, C.Wx2, c_b);
-    const uint32_t gt = one_of((cB | K80) - cA);                           // cell ids order like interior indices
-    const uint32_t iA = cA - (r_a << 1) - K01;
-    const uint32_t iB = cB - (r_b << 1) - K01 - gt;
-    const uint32_t q = (iB << 1) + p01 + K01;
+    const uint32_t jA = pk_mad(r_a, C.Wm2x2, c_a), jB = pk_mad(r_b, C.Wm2x2, c_b);
+    const uint32_t gt2 = (((jB | K80) - jA) >> 6) & 0x02020202u;           // 2 * (iB > iA)
+    const uint32_t iA = jA - K01;
+    const uint32_t q = (jB << 1) + p01 - gt2 - K01;                         // 2 * (iB - gt) + 1 + p
     lo = pk_mad(perm(0u, iA, 0x0c010c00u), C.obs_mul, perm(0u, q, 0x0c010c00u));
     hi = pk_mad(perm(0u, iA, 0x0c030c02u), C.obs_mul, perm(0u, q, 0x0c030c02u));
     if (ZERO) {

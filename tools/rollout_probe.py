@@ -33,3 +33,11 @@ run("streams in, obs only", **A, obs=obs, out_stride=N)
 run("streams in, reward+term+trunc only", **A, reward=rew, terminated=term, truncated=trunc, out_stride=N)
 run("sampled uniform, 4 trajectories out", sample_actions=True, **O)
 run("sampled uniform, nothing out", sample_actions=True)
+
+# BASELINE config 5: both players sample from [nS, 5] mixed-policy tables in the kernel
+rngp = np.random.default_rng(94)
+ta = SoccerBatch.mixed_policy_thresholds(rngp.dirichlet(np.ones(5) * 0.7, size=b.nS))
+tb = SoccerBatch.mixed_policy_thresholds(rngp.dirichlet(np.ones(5) * 0.7, size=b.nS))
+da = torch.from_numpy(ta.view(np.int16)).to(dev); db = torch.from_numpy(tb.view(np.int16)).to(dev)
+run("config 5: mixed-policy tables, nothing out", sample_actions=True, mix_a=da, mix_b=db)
+run("config 5: mixed-policy tables, 4 trajectories out", sample_actions=True, mix_a=da, mix_b=db, **O)
