@@ -10,7 +10,8 @@ episode returns after the timed region — BASELINE configs[3]).
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = 19 algorithmic bytes per env-step (SURVEY.md
 §8(d): read 6 B state + 2 B actions, write 6 B state + 5 B obs/reward/terminated/truncated) x lanes
-per launch / the average launch duration measured with HIP events on the kernel's own stream.
+per launch / ms_per_step, the host wall clock `value` is computed from; `roofline.achieved_device` /
+`frac_device` use device clock stamps captured around the K launches on the kernel's own stream instead.
 `cpu_baseline` = the CPU oracle (oracle/soccer_oracle.c, a port pinned bit-for-bit to the reference
 by tests/golden) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -78,13 +79,15 @@ def csrc_sha256():
     return h.hexdigest()
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, deadline_s):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.
 
     Runs in a parent process that has NOT touched the GPU (no torch import, no libsoccer_hip load): each rank
     is a fresh child `python bench.py <same flags>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly
     what torch.distributed.run would set.  Children inherit stdout, so rank 0's JSON line is the only one.
-    Returns the exit code: 0 only if every rank exited 0; the first failure ends the others."""
+    Returns the exit code: 0 only if every rank exited 0; the first failure ends the others, and so does the overall
+    deadline (a rank stuck in rendezvous or in a collective while the others wait for it: exit code 124).  Only the
+    children started here are ever signalled, and nothing is re-executed."""
     import socket
     import subprocess
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
@@ -94,7 +97,19 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    t_end = time.monotonic() + deadline_s
     rc, live = 0, set(range(n))
+
+    def stop_others(grace=5.0):
+        for q in live:
+            procs[q].terminate()              # exactly the children started above
+        t_kill = time.monotonic() + grace
+        for q in live:
+            try:
+                procs[q].wait(timeout=max(0.0, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[q].kill(); procs[q].wait()
+
     while live:
         for r in sorted(live):
             code = procs[r].poll()
@@ -104,8 +119,13 @@ def spawn_ranks(n, argv):
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
                 print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
-                for q in live:
-                    procs[q].terminate()          # exactly the children started above
+                stop_others(); live.clear()
+                break
+        if live and time.monotonic() > t_end:
+            print("bench.py: ranks %s still running after the %.0f s deadline (--rank-deadline); stopping them"
+                  % (sorted(live), deadline_s), file=sys.stderr)
+            stop_others(); live.clear()
+            rc = rc or 124
         time.sleep(0.05)
     return rc
 
@@ -115,10 +135,13 @@ def launcher_selftest(args, rank, world):
     one all_reduce, one JSON line from rank 0.  No GPU work and no measurement — never a bench result."""
     import torch
     import torch.distributed as dist
+    import datetime
     if args.selftest_fail_rank == rank:
         raise SystemExit(3)
+    if args.selftest_hang_rank == rank:
+        time.sleep(3600)                      # a rank that never reaches the rendezvous
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.collective_timeout))
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t)
@@ -148,11 +171,17 @@ def main():
     ap.add_argument("--no-vector-env", action="store_true", help="skip the VectorSoccerEnv(io='device') timing")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--rank-deadline", type=float, default=300.0,
+                    help="self-spawned ranks (python bench.py --gpus N): seconds after which ranks that are still running are "
+                         "stopped and the run fails with exit code 124")
+    ap.add_argument("--collective-timeout", type=float, default=120.0,
+                    help="timeout of the process group (rendezvous and every collective), seconds")
     args = ap.parse_args()
 
     # ---- rank bring-up: before anything touches the GPU -------------------------------------------
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))         # parent: no torch, no HIP
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rank_deadline))         # parent: no torch, no HIP
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -174,11 +203,13 @@ def main():
     dev = torch.device("cuda", dev_index)
     cdev = torch.device("cpu") if gloo else dev          # where collective operands live
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        pg_timeout = datetime.timedelta(seconds=args.collective_timeout)     # a stuck peer fails the job instead of hanging it
         if gloo:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
 
     from gym_soccer_littman94_amd import SoccerBatch
     from gym_soccer_littman94_amd.distributed import gather_lane_values, reduce_histogram, shard_range
@@ -229,15 +260,18 @@ def main():
                        term[k].data_ptr(), trunc[k].data_ptr(), None) for k in range(K)]
 
     def barrier():
+        # ONE host synchronisation: hipDeviceSynchronize covers the handle's own (non-blocking) stream as well as torch's.
+        # In the timed region it is called after soccer_timer_read has already seen the closing stamp, i.e. on an idle device.
         if world > 1:
             dist.barrier()
-        b.sync(); torch.cuda.synchronize()
+        torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
+    t_enq = t_seen = None
     if graph is not None:
-        b.graph_launch(graph, 1)
-        ev_ms = b.timer_read()
+        b.graph_launch(graph, 1); t_enq = time.perf_counter()
+        ev_ms = b.timer_read(); t_seen = time.perf_counter()
         if KG < K:                  # odd K: one eager launch on top of the captured even number
             b.timer_start()
             for k in range(KG, K):
@@ -251,10 +285,37 @@ def main():
         ev_ms = b.timer_stop()
     barrier()
     wall = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(tt[0]), float(tt[1])
+        # every rank's own clocks, so that a scaling line shows rank skew; the job's time is the slowest rank's
+        mine = torch.tensor([wall, ev_ms], dtype=torch.float64, device=cdev)
+        allr = torch.empty((world, 2), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu()
+        per_rank = [{"rank": r, "wall_us": float(allr[r, 0]) * 1e6, "launch_us": float(allr[r, 1]) * 1e3 / K} for r in range(world)]
+        wall, ev_ms = float(allr[:, 0].max()), float(allr[:, 1].max())
+
+    # ---- after the timed region: where the launches of a replay spend their time --------------------------
+    # The same K launches captured once more with a clock stamp between every two of them (a one-thread kernel: each
+    # adds one more kernel boundary, so the deltas are launch + ~1.5 us; what matters is how they differ along the
+    # replay).  Replayed right after an idle barrier like the timed region, three times; the last replay is reported.
+    launch_profile = None
+    if graph is not None and world == 1 and 2 <= KG <= 200:
+        b.graph_begin()
+        b.stamp(2)
+        for k in range(KG):
+            enqueue(k); b.stamp(3 + k)
+        gp = b.graph_end()
+        for _ in range(3):
+            barrier(); b.stamps_clear(2, KG + 1)
+            b.graph_launch(gp, 1); barrier()
+        ticks, khz = b.stamps(2, KG + 1)
+        d_us = np.diff(ticks.astype(np.int64)) / (khz * 1e-3)
+        launch_profile = {"what": "device-clock deltas between stamps placed after every launch of one %d-launch replay "
+                                  "(each delta = one step launch + one stamp kernel)" % KG,
+                          "us": [round(float(x), 3) for x in d_us],
+                          "first4_mean_us": float(d_us[:4].mean()), "rest_mean_us": float(d_us[4:].mean()) if KG > 4 else None}
+        b.graph_destroy(gp)
 
     # ---- after the timed region: episode returns from the trajectories the timed steps wrote ---------
     # (the only cross-GPU exchange: one all_gather of int8 per-lane returns + a 3-bin all_reduce)
@@ -288,7 +349,13 @@ def main():
     # ---- optional: fused T-step rollout (state in registers, same per-step results) -------------
     rollout = None
     if args.rollout > 0:
-        T = min(args.rollout, K)
+        T = args.rollout
+        del obs, rew, term, trunc, acts                  # the step buffers; the rollout gets its own [T, N] ones
+        torch.cuda.empty_cache()
+        acts = torch.randint(0, 5, (T, 2, N), dtype=torch.int8, device=dev, generator=g)
+        KA = T
+        obs = torch.empty((T, N), dtype=torch.int16, device=dev); rew = torch.empty((T, N), dtype=torch.int8, device=dev)
+        term = torch.empty((T, N), dtype=torch.uint8, device=dev); trunc = torch.empty((T, N), dtype=torch.uint8, device=dev)
         b.rollout(T, acts[0, 0], acts[0, 1], act_stride=2 * N, obs=obs, reward=rew, terminated=term,
                   truncated=trunc, out_stride=N)          # warm
         barrier()
@@ -305,7 +372,9 @@ def main():
         bytes_per = 7 + 12.0 / T                         # 2 B actions in, 5 B out, state amortised over T
         rollout = {"steps_fused": T, "env_steps_per_s": world * N * T / (r_ms * 1e-3),
                    "bytes_per_env_step": bytes_per,
-                   "achieved_GBps": bytes_per * world * N * T / (r_ms * 1e-3) / 1e9}
+                   "achieved_GBps": bytes_per * world * N * T / (r_ms * 1e-3) / 1e9,
+                   "frac_of_hbm_peak": bytes_per * world * N * T / (r_ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world),
+                   "kernel": "soccer::rollout_swar_kernel<0, %s, 1>" % ("true" if args.slip else "false")}
 
     # ---- optional: BASELINE config 5 shape — both players sample from [nS, 5] mixed policies in-kernel --
     selfplay = None
@@ -340,32 +409,40 @@ def main():
     vec_env = None
     if not args.no_vector_env and world == 1:
         from gym_soccer_littman94_amd import VectorSoccerEnv
-        with torch.cuda.device(dev):
-            v = VectorSoccerEnv(N, slip_prob=args.slip, seed=0, io="device", device=dev_index)
-            v.reset()
-            KV = max(200, min(K, 1000))
-            pairs = [{"player_a": acts[k % KA, 0], "player_b": acts[k % KA, 1]} for k in range(KV)]
-            for k in range(20):
-                v.step(pairs[k])
-            torch.cuda.synchronize()
-            tv = time.perf_counter()
-            for k in range(KV):
-                v.step(pairs[k])
-            torch.cuda.synchronize()
-            dv = time.perf_counter() - tv
-            o_, r_, te_, tr_, inf_ = v.step(pairs[0])
-            assert r_["player_a"].dtype == torch.float32 and bool((r_["player_a"] == -r_["player_b"]).all())
-            assert v.batch.misuse() == 0
-            vec_env = {"api": "VectorSoccerEnv(io='device').step(dict of int8 CUDA tensors)", "steps": KV,
-                       "us_per_step": dv / KV * 1e6, "env_steps_per_s": N * KV / dv,
-                       "bytes_per_env_step": 31,
-                       "note": "float32 rewards of both agents and infos['_final_observation'] are written by the step kernel; "
-                               "info[agent]['p'] is computed on access"}
-            v.close()
+        vec_env = {}
+        for key, info, nbytes, note in (
+                ("full", True, 31, "info=True: + final_observation, prob_code (info[agent]['p'] computed on access), int8 reward, episode histogram"),
+                ("lean", False, 27, "info=False: observations, float32 rewards of both agents, terminated, truncated, _final_observation")):
+            with torch.cuda.device(dev):
+                v = VectorSoccerEnv(N, slip_prob=args.slip, seed=0, io="device", device=dev_index, info=info)
+                v.reset()
+                KV = max(200, min(K, 1000))
+                pairs = [{"player_a": acts[k % KA, 0], "player_b": acts[k % KA, 1]} for k in range(KV)]
+                for k in range(20):
+                    v.step(pairs[k])
+                torch.cuda.synchronize()
+                tv = time.perf_counter()
+                for k in range(KV):
+                    v.step(pairs[k])
+                torch.cuda.synchronize()
+                dv = time.perf_counter() - tv
+                o_, r_, te_, tr_, inf_ = v.step(pairs[0])
+                assert r_["player_a"].dtype == torch.float32 and bool((r_["player_a"] == -r_["player_b"]).all())
+                assert bool((inf_["_final_observation"] == (te_["player_a"] | tr_["player_a"])).all())
+                assert v.batch.misuse() == 0
+                vec_env[key] = {"api": "VectorSoccerEnv(io='device', info=%s).step(dict of int8 CUDA tensors)" % info, "steps": KV,
+                                "us_per_step": dv / KV * 1e6, "env_steps_per_s": N * KV / dv,
+                                "bytes_per_env_step": nbytes, "note": note}
+                v.close()
 
     if rank == 0:
+        # roofline.achieved / frac follow from the SAME clock as `value`: the host wall clock around the K steps (barrier
+        # to barrier).  The device-side figure — clock stamps captured around the K launches, i.e. without the replay's
+        # start-up latency and the host's wake-up — is reported next to it as frac_device.
+        step_s = wall / K
+        achieved = ALGO_BYTES_PER_ENV_STEP * N / step_s / 1e9
         launch_s = ev_ms * 1e-3 / K
-        achieved = ALGO_BYTES_PER_ENV_STEP * N / launch_s / 1e9
+        achieved_dev = ALGO_BYTES_PER_ENV_STEP * N / launch_s / 1e9
         # HBM-side bytes per launch: from a separate rocprofv3 --pmc run (tools/collect_profile.py), reported only when
         # that run measured THIS workload with THESE kernel sources (sha256 of csrc/ recorded next to the number)
         traffic, traffic_source = None, None
@@ -397,12 +474,26 @@ def main():
                          "bound_note": "bytes counted at the L2<->fabric boundary (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits "
                                        "are included, and the ~%d MB working set of a run fits the 256 MB Infinity Cache when K is small"
                                        % ((12 * N + 7 * N * K) >> 20),
-                         "kernel": "soccer::step_kernel_swar<false, %s, false, 1>" % ("1|2" if args.slip else "0"),   # as rocprofv3 prints it
-                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
+                         "kernel": "soccer::step_kernel_swar<0, %s, false, 1>" % ("true" if args.slip else "false"),   # as rocprofv3 prints it
+                         "frac_from": "ms_per_step (host wall clock, the clock `value` uses)",
+                         "achieved_device": achieved_dev, "frac_device": achieved_dev / HBM_PEAK_GBPS,
+                         "launch_us": launch_s * 1e6, "device_region_us": ev_ms * 1e3,
+                         "host_overhead_us": wall * 1e6 - ev_ms * 1e3,
+                         # where the host's share of the timed region goes (graph mode, one rank): the hipGraphLaunch call,
+                         # from its return to the closing stamp being seen (device region + whatever start-up latency the
+                         # replay had left), and the one synchronisation that closes the region
+                         "host_timeline_us": None if t_enq is None or world > 1 else {
+                             "graph_launch_call": (t_enq - t0) * 1e6, "launch_return_to_stamp_seen": (t_seen - t_enq) * 1e6,
+                             "closing_sync": (t0 + wall - t_seen) * 1e6},
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
             "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
                          "gathered_last_returns": int(gathered.numel()), "gather_allreduce_ms": gather_ms,
                          "gathered_mean": float(gathered.to(torch.float32).mean())},
         }
+        if per_rank:
+            out["per_rank"] = per_rank
+        if launch_profile:
+            out["launch_profile"] = launch_profile
         if rollout:
             out["fused_rollout"] = rollout
         if selfplay:

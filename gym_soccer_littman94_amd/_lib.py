@@ -113,6 +113,9 @@ PROTOTYPES = {
     "soccer_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "soccer_timer_mark": (C.c_int, [C.c_void_p]),
     "soccer_timer_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "soccer_stamp": (C.c_int, [C.c_void_p, C.c_int32]),
+    "soccer_stamps_clear": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "soccer_stamps_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
     "soccer_graph_begin": (C.c_int, [C.c_void_p]),
     "soccer_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "soccer_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

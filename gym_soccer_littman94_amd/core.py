@@ -426,6 +426,19 @@ class SoccerBatch:
         self._check(self.lib.soccer_timer_read(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def stamp(self, slot):
+        """Enqueue (or capture) a device clock stamp into slot 0..255 of the handle's host-mapped block."""
+        self._check(self.lib.soccer_stamp(self.h, int(slot)))
+
+    def stamps_clear(self, first=0, count=256):
+        self._check(self.lib.soccer_stamps_clear(self.h, int(first), int(count)))
+
+    def stamps(self, first=0, count=256):
+        """(ticks[count] uint64, clock kHz) — the slots as they stand, no synchronisation; 0 = not written since cleared."""
+        t = np.zeros(int(count), np.uint64); khz = C.c_int32()
+        self._check(self.lib.soccer_stamps_read(self.h, int(first), int(count), t.ctypes.data, C.byref(khz)))
+        return t, int(khz.value)
+
     # -- hipGraph capture ----------------------------------------------------------------------
     def graph_begin(self):
         self._check(self.lib.soccer_graph_begin(self.h))

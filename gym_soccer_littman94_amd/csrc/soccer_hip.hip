@@ -28,6 +28,7 @@ struct soccer_graph {
     hipGraphExec_t exec = nullptr;
     uint64_t ticks = 0;       // ticks consumed by one replay
     int start_slot = 0;       // tick slot the first captured launch reads
+    bool stamped = false;     // soccer_timer_start / _mark were captured: a replay writes stamp slots 0 and 1
 };
 
 struct soccer_handle {
@@ -69,12 +70,16 @@ struct soccer_handle {
     swar::SlipConsts slip_c{}; bool slip_swar_ok = false;   // integer slip selection usable by the byte-parallel kernels
     size_t hist_slots = kHistSlots;         // per-wave histogram slots (a power of two; see soccer_create)
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
+    bool stamp_poll = false;                // the closing stamp of the last soccer_graph_launch was cleared first: poll it
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
     bool plan_ready = false;
     std::string err;
 };
+
+// the handle's host-mapped block: dwords 0 / 1 the sticky misuse words, from byte 64 on SOCCER_STAMP_SLOTS u64 clock stamps
+constexpr size_t kMappedBytes = 64 + 8 * SOCCER_STAMP_SLOTS;
 
 static thread_local std::string g_err;
 
@@ -217,8 +222,8 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     while (h->hist_slots < (n + 255) / 256) h->hist_slots <<= 1;
     CREATE_TRY(hipMalloc(&h->d_hist, sizeof(unsigned long long) * h->hist_slots * kHistStride));
     CREATE_TRY(hipMemset(h->d_hist, 0, sizeof(unsigned long long) * h->hist_slots * kHistStride));
-    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->misuse_host), 128, hipHostMallocMapped));
-    std::memset(h->misuse_host, 0, 128);
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->misuse_host), kMappedBytes, hipHostMallocMapped));
+    std::memset(h->misuse_host, 0, kMappedBytes);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_misuse), h->misuse_host, 0));
 
     P.next_cell = h->d_nc; P.isd = h->d_isd;
@@ -1166,7 +1171,7 @@ extern "C" int soccer_reset_stats(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemsetAsync(h->d_hist, 0, sizeof(unsigned long long) * h->hist_slots * kHistStride, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_misuse, 0, 128, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_misuse, 0, 64, h->stream));
     return SOCCER_OK;
 }
 
@@ -1213,15 +1218,43 @@ __global__ void stamp_kernel(unsigned long long* slot) {
     if (threadIdx.x == 0) *slot = wall_clock64();
 }
 
+static volatile unsigned long long* stamp_host(soccer_handle* h) {
+    return reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<uint8_t*>(h->misuse_host) + 64);
+}
+static unsigned long long* stamp_dev(soccer_handle* h) {
+    return reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(h->d_misuse) + 64);
+}
+
+extern "C" int soccer_stamp(soccer_handle* h, int32_t slot) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (slot < 0 || slot >= SOCCER_STAMP_SLOTS) return fail(h, SOCCER_E_INVALID, "stamp slot %d out of range (0..%d)", slot, SOCCER_STAMP_SLOTS - 1);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, h->stream, stamp_dev(h) + slot);
+    HIP_TRY(h, hipGetLastError());
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_stamps_clear(soccer_handle* h, int32_t first, int32_t count) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (first < 0 || count < 0 || first + count > SOCCER_STAMP_SLOTS) return fail(h, SOCCER_E_INVALID, "stamp range out of bounds");
+    for (int32_t i = 0; i < count; ++i) stamp_host(h)[first + i] = 0ull;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_stamps_read(soccer_handle* h, int32_t first, int32_t count, uint64_t* ticks, int32_t* khz) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (first < 0 || count < 0 || first + count > SOCCER_STAMP_SLOTS || (count && !ticks)) return fail(h, SOCCER_E_INVALID, "stamp range out of bounds");
+    for (int32_t i = 0; i < count; ++i) ticks[i] = stamp_host(h)[first + i];
+    if (khz) *khz = h->wall_clock_khz;
+    return SOCCER_OK;
+}
+
 extern "C" int soccer_timer_start(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->timer_stamped = h->capturing;
-    if (h->capturing) {
-        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<unsigned long long*>(h->d_misuse + 16));
-        HIP_TRY(h, hipGetLastError());
-        return SOCCER_OK;
-    }
+    if (h->capturing) return soccer_stamp(h, 0);
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     return SOCCER_OK;
 }
@@ -1230,9 +1263,7 @@ extern "C" int soccer_timer_mark(soccer_handle* h) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (h->capturing) {
         if (!h->timer_stamped) return fail(h, SOCCER_E_STATE, "soccer_timer_mark in a capture needs soccer_timer_start in the same capture");
-        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<unsigned long long*>(h->d_misuse + 18));
-        HIP_TRY(h, hipGetLastError());
-        return SOCCER_OK;
+        return soccer_stamp(h, 1);
     }
     h->timer_stamped = false;
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -1243,15 +1274,36 @@ extern "C" int soccer_timer_read(soccer_handle* h, float* elapsed_ms) {
     if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_timer_read during graph capture");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (h->timer_stamped) {                 // the stamps of the last replay of a graph that captured start / mark
-        for (uint32_t spins = 0;; ++spins) {
-            const hipError_t q = hipStreamQuery(h->stream);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
-            if (spins > 2000u) { (void)hipGetLastError(); HIP_TRY(h, hipStreamSynchronize(h->stream)); break; }
-            __builtin_ia32_pause();
+        volatile unsigned long long* st = stamp_host(h);
+        if (h->stamp_poll) {
+            // The closing stamp was zeroed before the (single) replay was enqueued and its kernel writes it to host-mapped
+            // memory: watching that word costs no runtime call at all — the host sees the end of the region ~1 us after
+            // the device reaches it.  (The runtime's own completion signal of the replay arrives ~13 us after the last
+            // kernel on an MI355X — the write-back of the dirty L2 lines and the signal path, tools/sync_cost.py — whether
+            // one waits for it in hipStreamSynchronize, in hipDeviceSynchronize or by polling an event recorded behind
+            // the replay; a host that only needs the device time does not have to.)
+            const auto t_start = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0; st[1] == 0ull; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 0xfffffu) == 0xfffffu) {                    // every few ms: has the stream died?
+                    const hipError_t e = hipStreamQuery(h->stream);
+                    if (e != hipSuccess && e != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "soccer_timer_read: %s", hipGetErrorString(e));
+                    if (e == hipSuccess && st[1] == 0ull) return fail(h, SOCCER_E_STATE, "soccer_timer_read: the stream is idle but the closing stamp was never written");
+                    if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                        return fail(h, SOCCER_E_HIP, "soccer_timer_read: no closing stamp after 60 s");
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            for (uint32_t spins = 0;; ++spins) {
+                const hipError_t q = hipStreamQuery(h->stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+                if (spins > 2000u) { (void)hipGetLastError(); HIP_TRY(h, hipStreamSynchronize(h->stream)); break; }
+                __builtin_ia32_pause();
+            }
+            (void)hipGetLastError();
         }
-        (void)hipGetLastError();
-        const volatile unsigned long long* st = reinterpret_cast<const volatile unsigned long long*>(h->misuse_host + 16);
         *elapsed_ms = (float)((double)(st[1] - st[0]) / (double)h->wall_clock_khz);
         return SOCCER_OK;
     }
@@ -1299,7 +1351,7 @@ extern "C" int soccer_graph_end(soccer_handle* h, soccer_graph** out) {
                     h->capture_calls);
     }
     soccer_graph* g = new soccer_graph();
-    g->graph = graph; g->ticks = h->capture_ticks; g->start_slot = h->capture_start_slot;
+    g->graph = graph; g->ticks = h->capture_ticks; g->start_slot = h->capture_start_slot; g->stamped = h->timer_stamped;
     hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(graph); delete g;
@@ -1323,6 +1375,9 @@ extern "C" int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t re
                                   sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
         h->tick_slot = g->start_slot;
     }
+    // one replay: zero the closing stamp first, so that soccer_timer_read can watch for it (several replays would each write it)
+    h->stamp_poll = replays == 1 && g->stamped;
+    if (h->stamp_poll) { stamp_host(h)[1] = 0ull; std::atomic_thread_fence(std::memory_order_seq_cst); }
     for (int32_t r = 0; r < replays; ++r) HIP_TRY(h, hipGraphLaunch(g->exec, h->stream));
     h->tick += g->ticks * (uint64_t)(replays > 0 ? replays : 0);
     return SOCCER_OK;

@@ -18,6 +18,10 @@ Two I/O modes:
     returned agents and `infos["_final_observation"]` are written by the step kernel itself (`float_rewards=True`, the
     default: +4 B per env-step and agent instead of a 5 us cast kernel per read); `float_rewards=False` leaves them to
     be computed on first access and `reward_int8` is then the zero-cost way to read player A's reward.
+    `info=False` is the lean form for loops that read observations, rewards and the done flags only: no `info[agent]["p"]`,
+    no `infos["final_observation"]`, no episode histogram, and (with float rewards) no int8 reward stream — 27 instead of 31
+    bytes per env-step and the step kernel's instantiation without the second observation index
+    (`infos["_final_observation"]`, the lanes whose episode just ended, stays).
 Per-lane randomness is Philox4x32-10 keyed by (seed, global lane id, tick): include/soccer_hip.h.
 """
 import numpy as np
@@ -85,7 +89,7 @@ class VectorSoccerEnv:
 
     def __init__(self, num_envs, width=5, height=4, slip_prob=0.0, seed=0, autoreset=True,
                  device=0, lane_offset=0, max_episode_steps=100, io="numpy", strict=True,
-                 envs_per_thread=0, player_a_policy=None, player_b_policy=None, copy=True, float_rewards=True):
+                 envs_per_thread=0, player_a_policy=None, player_b_policy=None, copy=True, float_rewards=True, info=True):
         assert io in ("numpy", "device"), "io must be 'numpy' or 'device'"
         assert not (player_a_policy is not None and player_b_policy is not None), \
             "Both players cannot have a policy. At least one must be None."
@@ -93,6 +97,7 @@ class VectorSoccerEnv:
         self.io = io
         self.strict = strict
         self.float_rewards = bool(float_rewards)
+        self.info = bool(info) or io != "device"    # the lean form exists for device io only
         self.copy = bool(copy)      # numpy io: return copies (gym.vector's default) or views over the staging block
         stream = None
         if io == "device":
@@ -102,7 +107,7 @@ class VectorSoccerEnv:
             stream = torch.cuda.current_stream(self._dev).cuda_stream   # results are ordered with torch work
         self._batch = SoccerBatch(self.num_envs, width, height, slip_prob, seed=seed, autoreset=autoreset,
                                   max_steps=max_episode_steps, device=device, lane_offset=lane_offset,
-                                  stream=stream, envs_per_thread=envs_per_thread)
+                                  stream=stream, envs_per_thread=envs_per_thread, step_stats=self.info)
         b = self._batch
         self.width, self.height, self.slip_prob = width + 2, height, slip_prob
         self.nS, self.nA = b.nS, b.nA
@@ -129,9 +134,11 @@ class VectorSoccerEnv:
             t, n, d = self._torch, self.num_envs, self._dev
             u16 = getattr(t, "uint16", t.int16)
             self._obs = t.zeros(n, dtype=u16, device=d); self._fin = t.zeros(n, dtype=u16, device=d)
-            self._rew = t.zeros(n, dtype=t.int8, device=d)
+            lean = not self.info
+            self._rew = None if (lean and self.float_rewards) else t.zeros(n, dtype=t.int8, device=d)
             self._term = t.zeros(n, dtype=t.uint8, device=d); self._trunc = t.zeros(n, dtype=t.uint8, device=d)
-            self._code = t.zeros(n, dtype=t.uint8, device=d)
+            self._code = None if lean else t.zeros(n, dtype=t.uint8, device=d)
+            if lean: self._fin = None
             self._prob = t.tensor(np.round(b.prob_table, 2), dtype=t.float64, device=d)
             # Everything step() returns is built ONCE: the result buffers are fixed, so the dicts of views over them
             # are too (the reference also hands back the same dict objects every call); what needs a kernel of its
@@ -152,9 +159,11 @@ class VectorSoccerEnv:
                 if 'player_a' in ags: rew_thunks['player_a'] = lambda: self._rew.to(t.float32)
                 if 'player_b' in ags: rew_thunks['player_b'] = lambda: 0.0 - self._rew.to(t.float32)      # :400-402, :243-244
                 self._ret_rew = _Lazy(rew_thunks, dirty=self._stale)
-            self._ret_p = _LazyInfo(lambda: self._prob[self._code.long()], dirty=self._stale)       # np.round(prob, 2) of the sampled transition (:405)
-            eager = {ag: self._ret_p for ag in ags}
-            eager["final_observation"] = {ag: self._fin for ag in ags}
+            eager = {}
+            if not lean:
+                self._ret_p = _LazyInfo(lambda: self._prob[self._code.long()], dirty=self._stale)       # np.round(prob, 2) of the sampled transition (:405)
+                eager = {ag: self._ret_p for ag in ags}
+                eager["final_observation"] = {ag: self._fin for ag in ags}
             if self.float_rewards:
                 eager["_final_observation"] = self._finished.view(t.bool)
                 self._ret_infos = eager
@@ -162,9 +171,10 @@ class VectorSoccerEnv:
                 self._ret_infos = _Lazy({"_final_observation": lambda: term_b | trunc_b}, eager, dirty=self._stale)
             from .._lib import StepArgs
             fptr = lambda ag: f32[ag].data_ptr() if ag in f32 else None
-            self._step_args = StepArgs(None, None, None, None, self._obs.data_ptr(), self._rew.data_ptr(),
-                                       self._term.data_ptr(), self._trunc.data_ptr(), self._code.data_ptr(),
-                                       self._fin.data_ptr(), None, fptr('player_a'), fptr('player_b'),
+            dptr = lambda x: None if x is None else x.data_ptr()
+            self._step_args = StepArgs(None, None, None, None, self._obs.data_ptr(), dptr(self._rew),
+                                       self._term.data_ptr(), self._trunc.data_ptr(), dptr(self._code),
+                                       dptr(self._fin), None, fptr('player_a'), fptr('player_b'),
                                        self._finished.data_ptr() if self.float_rewards else None)
             self._step_call = b.lib.batched_step_ex
             import ctypes
@@ -263,7 +273,8 @@ class VectorSoccerEnv:
 
     @property
     def reward_int8(self):
-        """device io: player A's reward of the last step as the int8 tensor the kernel wrote (-1 / 0 / +1), no cast."""
+        """device io: player A's reward of the last step as the int8 tensor the kernel wrote (-1 / 0 / +1), no cast
+        (None with info=False and float rewards: that stream is not written then)."""
         return self._rew
 
     def _raise_on_misuse(self):
@@ -295,7 +306,8 @@ class VectorSoccerEnv:
         self._needs_reset = False
 
     def episode_histogram(self):
-        """Counts of finished episodes by player A's return (-1, 0, +1)."""
+        """Counts of finished episodes by player A's return (-1, 0, +1); not collected with info=False."""
+        assert self.info, "the episode histogram is not collected with info=False"
         return self._batch.stats()[0]
 
     @property

@@ -37,6 +37,28 @@ def test_a_failing_rank_fails_the_run():
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
 
 
+def test_a_rank_that_hangs_is_stopped_at_the_deadline():
+    """One rank never reaches the rendezvous: the others block in it.  The parent's overall deadline stops every child
+    it started and the run fails — within the deadline plus the termination grace, not after the driver's whole budget."""
+    import time
+    t0 = time.monotonic()
+    r = _run("--gpus", "2", "--launcher-selftest", "--selftest-hang-rank", "1", "--rank-deadline", "8", "--collective-timeout", "60")
+    took = time.monotonic() - t0
+    assert r.returncode == 124, (r.returncode, r.stderr)
+    assert "still running after the 8 s deadline" in r.stderr
+    assert took < 40, took
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_a_stuck_peer_fails_the_collective_timeout_of_the_others():
+    """Without the parent (ranks started by a launcher): the process group's own timeout turns a missing peer into an
+    error of the waiting rank instead of an endless rendezvous."""
+    r = _run("--gpus", "2", "--launcher-selftest", "--collective-timeout", "5",
+             env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29513"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
 def test_under_a_launcher_it_does_not_spawn_again():
     # what torch.distributed.run sets for a 1-rank job: the process is the rank, no children
     r = _run("--gpus", "1", "--launcher-selftest",

@@ -406,3 +406,94 @@ def test_vector_env_strict_mode_reports_bad_device_actions():
     with pytest.raises(AssertionError, match="0..4"):
         vn.step({"player_a": np.full(64, 5), "player_b": np.zeros(64, np.int64)})
     vn.close()
+
+
+def test_one_handle_above_2_22_lanes_counts_every_episode():
+    """A single 2^23-lane handle stepped through batched_step_ex with the episode histogram on (VectorSoccerEnv's default):
+    the byte-parallel step launches one wave per 256 lanes — 32 768 of them here — and every wave must own its histogram
+    slot (round 2 had 16 384 slots and wave % 16384: two waves of one launch shared a slot without atomics).  The
+    histogram must equal the count of terminated | truncated, split by the sign of the reward, over all outputs."""
+    import torch
+    n, steps = 1 << 23, 130
+    dev = torch.device("cuda", 0)
+    b = SoccerBatch(n, 5, 4, 0.0, seed=11, autoreset=True, step_stats=True)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    acts = torch.randint(0, 5, (16, 2, n), dtype=torch.int8, device=dev, generator=g)
+    u16 = getattr(torch, "uint16", torch.int16)
+    obs = torch.empty(n, dtype=u16, device=dev); rew = torch.empty(n, dtype=torch.int8, device=dev)
+    term = torch.empty(n, dtype=torch.uint8, device=dev); trunc = torch.empty(n, dtype=torch.uint8, device=dev)
+    fin = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    b.reset(); b.reset_stats()
+    want = np.zeros(3, np.int64); ends = 0
+    for k in range(steps):
+        b.step(acts[k % 16, 0], acts[k % 16, 1], obs=obs, reward=rew, terminated=term, truncated=trunc, finished=fin)
+        b.sync()
+        done = (term | trunc) != 0
+        assert bool((fin.bool() == done).all())
+        for i, v in enumerate((-1, 0, 1)):
+            want[i] += int(((rew == v) & done).sum())
+        ends += int(done.sum())
+        assert int(((rew != 0) & ~done).sum()) == 0          # a reward only on the step that ends an episode
+    hist, misuse = b.stats()
+    assert misuse == 0 and ends == want.sum() and want[1] > n // 2      # every lane truncated at least once in 130 steps
+    np.testing.assert_array_equal(hist.astype(np.int64), want)
+    b.close()
+
+
+def test_last_return_rides_on_the_byte_parallel_step():
+    """last_return (A's return of the lane's most recently finished episode) no longer forces the per-lane kernel: the
+    byte-parallel step writes it with a read-modify-write of the thread's own dword, only on steps that end an episode;
+    lanes whose episode goes on keep what the stream held.  Against the oracle, with a sentinel in the stream."""
+    from oracle.oracle import Oracle
+    n = 4096
+    rng = np.random.default_rng(8)
+    for slip in (0.0, 0.2):
+        b = SoccerBatch(n, 5, 4, slip, seed=21, autoreset=True, step_stats=False)
+        o = Oracle(5, 4, slip, n=n, seed=21, autoreset=True)
+        A = b.alloc(n, np.int8); B = b.alloc(n, np.int8); rew = b.alloc(n, np.int8)
+        last = b.alloc(n, np.int8).fill(0x55)
+        b.reset(); o.reset()
+        want = np.full(n, 0x55, np.int8)
+        for _ in range(140):
+            a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+            A.upload(a[0]); B.upload(a[1])
+            b.step(A, B, reward=rew, last_return=last)
+            c = o.step(a[0], a[1])
+            done = (c["terminated"] | c["truncated"]) != 0
+            want = np.where(done, c["reward"], want)
+            np.testing.assert_array_equal(rew.download(), c["reward"])
+            np.testing.assert_array_equal(last.download(), want)
+        assert (want != 0x55).all()
+        b.close()
+
+
+@pytest.mark.parametrize("slip", [0.0, 0.2])
+def test_lean_device_vector_env_returns_what_the_full_one_does(slip):
+    """VectorSoccerEnv(io="device", info=False): the step kernel's instantiation without final_obs / prob_code / histogram
+    and without the int8 reward stream (27 B per env-step).  Same seed, same actions: observations, float32 rewards of
+    both agents, terminated, truncated and infos["_final_observation"] equal the full env's at every step."""
+    import torch
+    n = 8192 + 4
+    dev = torch.device("cuda", 0)
+    full = VectorSoccerEnv(n, slip_prob=slip, seed=3, io="device")
+    lean = VectorSoccerEnv(n, slip_prob=slip, seed=3, io="device", info=False)
+    assert lean.reward_int8 is None
+    of, _ = full.reset(); ol, _ = lean.reset()
+    assert bool((of["player_a"] == ol["player_a"]).all())
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    for k in range(150):
+        a = torch.randint(0, 5, (2, n), dtype=torch.int8, device=dev, generator=g)
+        act = {"player_a": a[0], "player_b": a[1]}
+        o1, r1, te1, tr1, i1 = full.step(act)
+        o2, r2, te2, tr2, i2 = lean.step(act)
+        for ag in ("player_a", "player_b"):
+            assert bool((o1[ag] == o2[ag]).all()) and bool((r1[ag] == r2[ag]).all())
+            assert r2[ag].dtype == torch.float32
+            assert bool((te1[ag] == te2[ag]).all()) and bool((tr1[ag] == tr2[ag]).all())
+        assert bool((i1["_final_observation"] == i2["_final_observation"]).all())
+        assert "final_observation" not in i2 and "player_a" not in i2
+    assert lean.batch.misuse() == 0
+    with pytest.raises(AssertionError):
+        lean.episode_histogram()
+    full.close(); lean.close()

@@ -165,3 +165,35 @@ def test_lazy_result_dicts_of_the_device_vector_env():
     assert top["player_a"]["p"] == "p-array" and top["final_observation"]["player_a"] == "fin" and top["_final_observation"] == "mask"
     top.invalidate()
     assert top["player_a"] is info and "_final_observation" in top
+
+
+def test_numpy_philox_known_answers_and_draw_convention():
+    """tests/philox_np.py (used by tests/test_gpu_fixture_pin.py instead of the oracle): Random123's kat_vectors for
+    philox4x32 with 10 rounds, and the ABI-3 bits -> uniform convention against its definition in include/soccer_hip.h."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from philox_np import lane_words, philox4x32_10, step_draws
+    kat = [(([0, 0, 0, 0], [0, 0]), [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           (([0xffffffff] * 4, [0xffffffff] * 2), [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           (([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]), [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for (ctr, key), want in kat:
+        got = philox4x32_10([ctr[0]], [ctr[1]], [ctr[2]], [ctr[3]], key[0], key[1])[:, 0]
+        assert [int(x) for x in got] == want
+    seed, lanes = 0x1234567890abcdef, np.array([0, 1, 2, 3, 4, 7, (1 << 34) + 5], np.uint64)
+    for tick in (0, 1, 6, 7, 8, 1234567, (1 << 33) + 3):
+        # slip > 0: the tick's own block, 30 + 2 bits of the lane's word
+        w = lane_words(seed, lanes, tick)
+        for j, g in enumerate(lanes.tolist()):
+            q = g >> 2
+            blk = philox4x32_10([q & 0xffffffff], [q >> 32], [tick & 0xffffffff], [tick >> 32], seed & 0xffffffff, seed >> 32)[:, 0]
+            assert int(w[j]) == int(blk[g & 3])
+        u, ur = step_draws(seed, lanes, tick, 0.2)
+        np.testing.assert_array_equal(u, ((w >> 2).astype(np.float64) + 0.5) / 2.0 ** 30)
+        np.testing.assert_array_equal(ur, ((w & 3).astype(np.float64) + 0.5) / 4.0)
+        assert ((u > 0) & (u < 1)).all()
+        # slip == 0: eight ticks share the block of tick >> 3; nibble (tick & 7) ^ 1
+        w8 = lane_words(seed, lanes, tick >> 3)
+        u0, ur0 = step_draws(seed, lanes, tick, 0.0)
+        nib = (w8.astype(np.int64) >> (4 * ((tick & 7) ^ 1))) & 15
+        np.testing.assert_array_equal(u0, ((nib >> 2) + 0.5) / 4.0)
+        np.testing.assert_array_equal(ur0, ((nib & 3) + 0.5) / 4.0)
