@@ -412,7 +412,7 @@ def main():
         vec_env = {}
         for key, info, nbytes, note in (
                 ("full", True, 31, "info=True: + final_observation, prob_code (info[agent]['p'] computed on access), int8 reward, episode histogram"),
-                ("lean", False, 27, "info=False: observations, float32 rewards of both agents, terminated, truncated, _final_observation")):
+                ("lean", False, 23, "info=False: observations, player_a's float32 reward (player_b's = its negation, on access), terminated, truncated, _final_observation")):
             with torch.cuda.device(dev):
                 v = VectorSoccerEnv(N, slip_prob=args.slip, seed=0, io="device", device=dev_index, info=info)
                 v.reset()

@@ -19,8 +19,9 @@ Two I/O modes:
     default: +4 B per env-step and agent instead of a 5 us cast kernel per read); `float_rewards=False` leaves them to
     be computed on first access and `reward_int8` is then the zero-cost way to read player A's reward.
     `info=False` is the lean form for loops that read observations, rewards and the done flags only: no `info[agent]["p"]`,
-    no `infos["final_observation"]`, no episode histogram, and (with float rewards) no int8 reward stream — 27 instead of 31
-    bytes per env-step and the step kernel's instantiation without the second observation index
+    no `infos["final_observation"]`, no episode histogram, no int8 reward stream, and ONE float32 reward stream (player_a's
+    when both agents are returned; player_b's is its negation, computed on first access) — 23 instead of 31 bytes per
+    env-step and the step kernel's instantiation without the second observation index
     (`infos["_final_observation"]`, the lanes whose episode just ended, stays).
 Per-lane randomness is Philox4x32-10 keyed by (seed, global lane id, tick): include/soccer_hip.h.
 """
@@ -151,9 +152,16 @@ class VectorSoccerEnv:
             self._stale = []            # lazy dicts that computed something since the last step
             f32 = {}
             if self.float_rewards:      # the kernel writes the floats (and terminated | truncated) next to the int8 stream
-                f32 = {ag: t.zeros(n, dtype=t.float32, device=d) for ag in ags}
+                # lean form: the game is zero-sum (:400-402), so ONE float stream is written — the first returned agent's —
+                # and the other agent's reward is its negation, computed on first access
+                written = ags[:1] if lean else ags
+                f32 = {ag: t.zeros(n, dtype=t.float32, device=d) for ag in written}
                 self._finished = t.zeros(n, dtype=t.uint8, device=d)
-                self._ret_rew = dict(f32)
+                if len(written) == len(ags):
+                    self._ret_rew = dict(f32)
+                else:
+                    first = f32[ags[0]]
+                    self._ret_rew = _Lazy({ags[1]: lambda: 0.0 - first}, dict(f32), dirty=self._stale)
             else:
                 rew_thunks = {}
                 if 'player_a' in ags: rew_thunks['player_a'] = lambda: self._rew.to(t.float32)

@@ -471,7 +471,8 @@ def test_last_return_rides_on_the_byte_parallel_step():
 @pytest.mark.parametrize("slip", [0.0, 0.2])
 def test_lean_device_vector_env_returns_what_the_full_one_does(slip):
     """VectorSoccerEnv(io="device", info=False): the step kernel's instantiation without final_obs / prob_code / histogram
-    and without the int8 reward stream (27 B per env-step).  Same seed, same actions: observations, float32 rewards of
+    without the int8 reward stream and with one float32 reward stream (23 B per env-step; player_b's reward is the negation of
+    player_a's, computed on access).  Same seed, same actions: observations, float32 rewards of
     both agents, terminated, truncated and infos["_final_observation"] equal the full env's at every step."""
     import torch
     n = 8192 + 4

@@ -11,8 +11,8 @@ tests/golden/threshold_draws.json.
     tools/find_threshold_draws.py 0.15 0.4 ...    search these slips and MERGE their hits into the existing file
 
 (The entries of 0.1 / 0.2 / 0.3 / 0.5 date from ABI 2, u = m * 2^-30 and c' = ceil(sum * 2^30): m in {c' - 1, c'}.  As
-c is c' or c' - 1 they still sit on or next to a threshold — within {c - 1, c, c + 1} — including the draws exactly on
-0.1's mathematically dyadic threshold 27/32, marked "danger": the ones that needed a float64 walk in the kernels then.)
+c is c' or c' - 1 they still sit on or next to a threshold — within {c - 1, c, c + 1}.  Entries marked "danger" are draws
+exactly ON a mathematically dyadic threshold such as 0.1's 27/32: the ones that needed a float64 walk in the kernels then.)
 """
 import json
 import os
@@ -66,58 +66,27 @@ def main():
     if slips:
         res = json.load(open(out)); assert res["seed"] == seed
         res["hits"] = [h for h in res["hits"] if h["slip"] not in slips]
-    for slip in (slips or (0.2, 0.3, 0.5, 0.1)):
+    q = np.arange(n_lanes // 4, dtype=np.uint64)
+    for slip in (slips or (0.2, 0.3, 0.5, 0.1, 0.15, 0.4, 2.0 / 3.0)):
         th = thresholds(slip)
         targets = {}
         for name, c, t in th:
-            x = t * 2.0 ** 30 - 0.5
-            cb = int(np.ceil(x))
+            cb = int(np.ceil(t * 2.0 ** 30 - 0.5))
             for m in (cb - 1, cb):
                 if 0 <= m < (1 << 30):
                     targets.setdefault(m, []).append((name, c))
         tarr = np.array(sorted(targets), np.uint32)
-        q = np.arange(n_lanes // 4, dtype=np.uint64)
         found = 0
         for tick in range(ticks):
-            w = philox_blocks(q, tick, seed)
-            m = w >> 2
-            hit = np.isin(m, tarr)
-            for j, qi in zip(*np.nonzero(hit)):
-                g = int(qi) * 4 + int(j)
-                res["hits"].append({"slip": slip, "lane": g, "tick": tick, "m": int(m[j, qi]),
+            m = philox_blocks(q, tick, seed) >> 2
+            for j, qi in zip(*np.nonzero(np.isin(m, tarr))):
+                res["hits"].append({"slip": slip, "lane": int(qi) * 4 + int(j), "tick": tick, "m": int(m[j, qi]),
                                     "thresholds": [list(x) for x in targets[int(m[j, qi])]]})
                 found += 1
-        print("slip %.2f: %d draws on/next to a threshold in %d lanes x %d ticks" % (slip, found, n_lanes, ticks), file=sys.stderr)
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "threshold_draws.json")
-    slips = [float(x) for x in sys.argv[1:]]
-    res = {"seed": seed, "hits": []}
-    if slips:
-        res = json.load(open(out)); assert res["seed"] == seed
-        res["hits"] = [h for h in res["hits"] if h["slip"] not in slips]
-    for slip in (slips or (0.2, 0.3, 0.5, 0.1)):
-        th = thresholds(slip)
-        targets = {}
-        for name, c, t in th:
-            x = t * 2.0 ** 30 - 0.5
-            cb = int(np.ceil(x))
-            for m in (cb - 1, cb):
-                if 0 <= m < (1 << 30):
-                    targets.setdefault(m, []).append((name, c))
-        tarr = np.array(sorted(targets), np.uint32)
-        q = np.arange(n_lanes // 4, dtype=np.uint64)
-        found = 0
-        for tick in range(ticks):
-            w = philox_blocks(q, tick, seed)
-            m = w >> 2
-            hit = np.isin(m, tarr)
-            for j, qi in zip(*np.nonzero(hit)):
-                g = int(qi) * 4 + int(j)
-                res["hits"].append({"slip": slip, "lane": g, "tick": tick, "m": int(m[j, qi]),
-                                    "thresholds": [list(x) for x in targets[int(m[j, qi])]]})
-                found += 1
-        print("slip %.2f: %d draws on/next to a threshold in %d lanes x %d ticks" % (slip, found, n_lanes, ticks), file=sys.stderr)
-        # thresholds whose scaled value is (almost) an integer although the sums are not exact: the kernels send the
-        # lane that draws exactly that integer down the float64 path — find such draws (p = 2^-30 each)
+        print("slip %.4f: %d draws on/next to a threshold in %d lanes x %d ticks" % (slip, found, n_lanes, ticks), file=sys.stderr)
+        # thresholds that are dyadic rationals mathematically (27/32 at slip 0.1 ...) although the float64 sums that form
+        # them are not exact: under ABI 2 a draw exactly ON such an integer needed the float64 walk in the kernels
+        # ("danger"); such draws are searched for specifically (p = 2^-30 each)
         danger = {}
         for name, c, t in th:
             x = t * 2.0 ** 30; r = round(x)
@@ -126,15 +95,14 @@ def main():
         if danger:
             darr = np.array(sorted(danger), np.uint32); got = 0
             for tick in range(ticks, ticks + 1400):
-                w = philox_blocks(q, tick, seed); m = w >> 2
-                hit = np.isin(m, darr)
-                for j, qi in zip(*np.nonzero(hit)):
+                m = philox_blocks(q, tick, seed) >> 2
+                for j, qi in zip(*np.nonzero(np.isin(m, darr))):
                     res["hits"].append({"slip": slip, "lane": int(qi) * 4 + int(j), "tick": tick, "m": int(m[j, qi]),
                                         "thresholds": [list(x) for x in danger[int(m[j, qi])]], "danger": True})
                     got += 1
                 if got >= 3:
                     break
-            print("slip %.2f: %d draws exactly on the dangerous integer(s) %s" % (slip, got, sorted(danger)), file=sys.stderr)
+            print("slip %.4f: %d draws exactly on the dyadic integer(s) %s" % (slip, got, sorted(danger)), file=sys.stderr)
     with open(out, "w") as f:
         json.dump(res, f, indent=0)
     print("wrote", os.path.normpath(out), len(res["hits"]), "hits")
