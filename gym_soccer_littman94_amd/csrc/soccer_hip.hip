@@ -68,6 +68,7 @@ struct soccer_handle {
     // byte-parallel step (soccer_swar.hpp)
     swar::Consts swar_c{}; bool swar_ok = false;
     swar::SlipConsts slip_c{}; bool slip_swar_ok = false;   // integer slip selection usable by the byte-parallel kernels
+    uint32_t* d_slip_lut = nullptr;         // SlipTables::lut + T for the table form of the selection (when lut_ok)
     size_t hist_slots = kHistSlots;         // per-wave histogram slots (a power of two; see soccer_create)
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
     bool stamp_poll = false;                // the closing stamp of the last soccer_graph_launch was cleared first: poll it
@@ -117,7 +118,7 @@ static void free_handle(soccer_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_slip_lut};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -247,6 +248,14 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
         CREATE_TRY(hipMemcpy(h->d_sub, ST.sub, sizeof(ST.sub), hipMemcpyHostToDevice));
         P.sub = h->d_sub;
         h->slip_swar_ok = ST.swar_ok;
+        static_assert(kSlipLutWords == kSlipLdsWords && kSlipBuckets == 16384 && kSlipThresholds == 40, "table layout shared with the kernels");
+        if (ST.lut_ok) {
+            std::vector<uint32_t> img(kSlipLdsWords, 0xFFFFFFFFu);
+            std::memcpy(img.data(), ST.lut, kSlipBuckets);
+            std::memcpy(img.data() + kSlipBuckets / 4, ST.T, sizeof(ST.T));
+            CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_slip_lut), img.size() * sizeof(uint32_t)));
+            CREATE_TRY(hipMemcpy(h->d_slip_lut, img.data(), img.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         h->slip_c = swar::SlipConsts{};
         for (int i = 0; i < 9; ++i) h->slip_c.CB[i] = ST.CB[i];
         h->slip_c.c_off = ST.c_off;
@@ -542,8 +551,10 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
             RolloutSwar RS{P.state, P.state_stride, P.first, P.n, P.lane_offset, P.tick_in, P.tick_out, P.hist, P.misuse,
                            P.policy_a, P.policy_b, P.key0, P.key1,
-                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.hist_mask, R0.nS, 0, 0u};
-            size_t smem = 36 * sizeof(uint32_t);
+                           h->swar_c, h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.hist_mask, R0.nS, 0, 0u, 0u, h->d_slip_lut};
+            const int sm = !h->slip ? 0 : (h->d_slip_lut ? 2 : 1);    // slip selection: none / threshold by threshold / by table
+            size_t smem = 36 * sizeof(uint32_t);        // (the bucket table of sm == 2 is static LDS of the kernel)
+            RS.tab_off = (uint32_t)(smem / sizeof(uint32_t));
             const bool fixed = P.policy_a || P.policy_b;
             // both sides sampled from mixed-policy tables whose 16-byte rows fit LDS: the shape of config 5
             const bool both_mix = dyn && !fixed && io.sample_actions && io.mix_a && io.mix_b &&
@@ -573,7 +584,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                                 : (!io.sample_actions && P.policy_b && !P.policy_a && io.act_a) ? 5 : 3;
 #define LAUNCH_D(SV) do { if (dm == 0) LAUNCH_S(0, SV); else if (dm == 1) LAUNCH_S(1, SV); else if (dm == 2) LAUNCH_S(2, SV); \
                           else if (dm == 4) LAUNCH_S(4, SV); else if (dm == 5) LAUNCH_S(5, SV); else LAUNCH_S(3, SV); } while (0)
-            if (!h->slip) LAUNCH_D(false); else LAUNCH_D(true);
+            if (sm == 0) LAUNCH_D(0); else if (sm == 1) LAUNCH_D(1); else LAUNCH_D(2);
 #undef LAUNCH_D
 #undef LAUNCH_S
 #undef LAUNCH_G

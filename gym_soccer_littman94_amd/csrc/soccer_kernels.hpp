@@ -1329,7 +1329,15 @@ struct RolloutSwar {       // everything the kernel needs, and nothing else (Ker
     uint32_t hist_mask;
     int32_t nS; int32_t lds_tables;
     uint32_t act_off;                       // dword offset of the action staging area in dynamic LDS (16 x 256 dwords per workgroup)
+    uint32_t tab_off;                       // dword offset of the mixed-policy / fixed-policy tables in dynamic LDS
+    const uint32_t* slip_lut;               // SLIPM == 2: SlipTables::lut (kSlipBuckets bytes) followed by SlipTables::T
 };
+
+// where the slip selection of a byte-parallel kernel reads its thresholds: SLIPM == 1 the nine rows of quarter points
+// (compared one by one, for the slips whose thresholds crowd a table bucket), SLIPM == 2 the bucket table + the ascending
+// threshold list (swar::slip_select4_lut)
+struct SlipSrc { const swar::Quad* sub; const uint8_t* lut; const uint32_t* T; };
+constexpr int kSlipLutWords = 4096 + 40;        // = soccer::kSlipLdsWords (soccer_slip.hpp is host-only)
 
 // A mixed-policy row holds four 16-bit cumulative thresholds t0 <= t1 <= t2 <= t3 (values 0..2^15) as two dwords; the
 // action is the number of them that are <= the player's 15-bit draw h.  With `hs` = h in both halves and bit 15 set,
@@ -1358,18 +1366,16 @@ __device__ __forceinline__ uint32_t draw_b15(uint32_t wm) { return swar::perm(0u
 // Randomness (include/soccer_hip.h): with SLIP one step/reset block per tick; without, one block per EIGHT ticks — the
 // thread keeps it transposed (swar::transpose4) in p0..p3, p0 serving the current pair of ticks — which takes the Philox
 // rounds from ~45 to ~6 vector instructions per step; sampled actions take the lane's word of the tick's purpose-1 block.
-template <int DYNM, bool SLIP, bool GENERAL, int GEO>
-__device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const swar::Quad* sub,
+template <int DYNM, int SLIPM, bool GENERAL, int GEO>
+__device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const SlipSrc& slip,
                                                    const uint2* mix_a_in, const uint2* mix_b_in, const int8_t* pol_a_in, const int8_t* pol_b_in,
                                                    uint32_t* act_lds,
                                                    unsigned long long i0, unsigned long long tick0, swar::Group& S,
                                                    uint32_t& fin_tot, uint32_t& nz_tot, uint32_t& neg_tot,
                                                    uint32_t (&acc)[4], uint32_t& frozen_any, uint32_t& bad_any) {
     constexpr bool DYN = DYNM != 0;
-#ifndef SOCCER_ROLLOUT_STAGED
-#define SOCCER_ROLLOUT_STAGED 1         // 0: lab builds only (tools/lib_ab.sh): one prefetched action load per step
-#endif
-    constexpr bool STAGED = SOCCER_ROLLOUT_STAGED && (DYNM == 0 || DYNM == 4 || DYNM == 5);   // action streams staged through LDS, eight steps at a time
+    constexpr bool SLIP = SLIPM != 0;
+    constexpr bool STAGED = DYNM == 0 || DYNM == 4 || DYNM == 5;        // action streams staged through LDS, eight steps at a time
     constexpr bool TRUSTED = DYNM == 1 || DYNM == 2;                    // both sides sampled in 0..4 by the kernel itself
     const bool sample = DYNM == 1 || DYNM == 2 || (DYNM == 3 && IO.sample_actions);
     const uint4* mix_ab = DYNM == 2 ? reinterpret_cast<const uint4*>(mix_a_in) : nullptr;   // LDS rows { a: x, y; b: z, w }
@@ -1476,7 +1482,9 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         if (SLIP) {
             const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), R.key0, R.key1);
             uint32_t k4 = 0u;
-            swar::slip_select4(R.L, sub, TRUSTED ? a4 : swar::canon4(a4), TRUSTED ? b4 : swar::canon4(b4), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+            const uint32_t ca4 = TRUSTED ? a4 : swar::canon4(a4), cb4 = TRUSTED ? b4 : swar::canon4(b4);
+            if (SLIPM == 2) swar::slip_select4_lut(slip.lut, slip.T, R.L.c_off, ca4, cb4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+            else swar::slip_select4(R.L, slip.sub, ca4, cb4, blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
             rnd = swar::Rand4{k4 << 6, swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> C.isd_shift};
         } else {
             if (t == 0u && s != 0) {
@@ -1521,28 +1529,36 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     neg_tot += GENERAL ? neg_loc : (neg_loc - nz_loc) / 7u;             // (pos + 8 neg) - (pos + neg) = 7 neg
 }
 
-template <int DYNM, bool SLIP, int GEO = 0>
+template <int DYNM, int SLIPM, int GEO = 0>
 __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar R, const RolloutIO IO) {
+    constexpr bool SLIP = SLIPM != 0;
     constexpr bool DYN = DYNM >= 2;          // the forms that look something up by the observation
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     HistAcc<false> hist; hist.init_at(R.hist, R.hist_mask);
-    // LDS: [0, 36) the nine threshold rows (SLIP), then (DYN, when they fit) the mixed-policy rows — DYNM == 2: one 16-byte
-    // row { a's four thresholds, b's four } per state; DYNM == 3: mix_a rows, then mix_b rows (8 B per state) — and the
-    // two fixed policies (1 B per state)
-    const swar::Quad* sub = R.sub;
+    // LDS: the slip thresholds — SLIPM == 1: dynamic [0, 36) the nine rows; SLIPM == 2: a STATIC array (its address is an
+    // immediate of the ds_read, not an add per lane) holding the bucket table and the ascending list — then, dynamic from
+    // R.tab_off (DYN, when they fit), the mixed-policy rows — DYNM == 2: one 16-byte row { a's
+    // four thresholds, b's four } per state; DYNM == 3: mix_a rows, then mix_b rows (8 B per state) — and the two fixed
+    // policies (1 B per state), then from R.act_off the action staging area
+    SlipSrc slip{R.sub, nullptr, nullptr};
     const uint2* mix_a = reinterpret_cast<const uint2*>(IO.mix_a);
     const uint2* mix_b = reinterpret_cast<const uint2*>(IO.mix_b);
     const int8_t* pol_a = DYNM == 3 || DYNM == 4 ? R.policy_a : nullptr; const int8_t* pol_b = DYNM == 3 || DYNM == 5 ? R.policy_b : nullptr;
     const bool sample = DYNM == 2 || (DYNM == 3 && IO.sample_actions);
     if (SLIP || (DYN && R.lds_tables)) {
-        if (SLIP) { if (threadIdx.x < 36) smem[threadIdx.x] = reinterpret_cast<const uint32_t*>(R.sub)[threadIdx.x];
-                    sub = reinterpret_cast<const swar::Quad*>(smem); }
+        if (SLIPM == 1) { if (threadIdx.x < 36) smem[threadIdx.x] = reinterpret_cast<const uint32_t*>(R.sub)[threadIdx.x];
+                          slip.sub = reinterpret_cast<const swar::Quad*>(smem); }
+        if (SLIPM == 2) {
+            __shared__ __attribute__((aligned(16))) uint32_t s_slip[SLIPM == 2 ? kSlipLutWords : 4];
+            for (int i = threadIdx.x; i < kSlipLutWords; i += kBlock) s_slip[i] = R.slip_lut[i];
+            slip.lut = reinterpret_cast<const uint8_t*>(s_slip); slip.T = s_slip + kSlipLutWords - 40;
+        }
         if (DYNM == 2) {                     // the host picks this shape only when the rows fit
-            uint4* lab = reinterpret_cast<uint4*>(smem + 36);
+            uint4* lab = reinterpret_cast<uint4*>(smem + R.tab_off);
             for (int i = threadIdx.x; i < R.nS; i += kBlock) { const uint2 xa = mix_a[i], xb = mix_b[i]; lab[i] = make_uint4(xa.x, xa.y, xb.x, xb.y); }
             mix_a = reinterpret_cast<const uint2*>(lab); mix_b = nullptr;
         } else if (DYN && R.lds_tables) {
-            uint2* la = reinterpret_cast<uint2*>(smem + 36); uint2* lb = la + R.nS;
+            uint2* la = reinterpret_cast<uint2*>(smem + R.tab_off); uint2* lb = la + R.nS;
             int8_t* pa = reinterpret_cast<int8_t*>(lb + R.nS); int8_t* pb = pa + ((R.nS + 15) & ~15);
             if (sample && mix_a) { for (int i = threadIdx.x; i < R.nS; i += kBlock) la[i] = mix_a[i]; mix_a = la; }
             if (sample && mix_b) { for (int i = threadIdx.x; i < R.nS; i += kBlock) lb[i] = mix_b[i]; mix_b = lb; }
@@ -1569,8 +1585,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
         const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
         const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
-        if (special) rollout_swar_group<DYNM, SLIP, true, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
-        else rollout_swar_group<DYNM, SLIP, false, GEO>(R, IO, sub, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        if (special) rollout_swar_group<DYNM, SLIPM, true, GEO>(R, IO, slip, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYNM, SLIPM, false, GEO>(R, IO, slip, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
         uint8_t* sw = R.state + i0;
         *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
         *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;

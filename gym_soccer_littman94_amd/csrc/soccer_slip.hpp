@@ -27,6 +27,9 @@
 
 namespace soccer {
 
+constexpr int kSlipBucketBits = 14, kSlipBuckets = 1 << kSlipBucketBits, kSlipThresholds = 40;
+constexpr int kSlipLdsWords = kSlipBuckets / 4 + kSlipThresholds;       // what a kernel stages: the table, then the thresholds
+
 struct SlipTables {
     double w[4];                 // weights c0..c3 of the four combination classes, float64 exactly as :211-222 evaluates them
     double B[9];                 // cumulative weight after each ACTIVE (non-zero) combination in reference order, +inf beyond
@@ -42,6 +45,14 @@ struct SlipTables {
     bool swar_ok;                // the byte-parallel kernels may use the integer decision: slip_int == 1, the active combinations
                                  // are consecutive ids, and a two-way list's first entry ends where a four-way list's second does
                                  // (one quarter index then serves both)
+    // Table form of the same decision (swar::slip_select4_lut).  Every active combination owns four consecutive
+    // thresholds — its quarter points 1, 2, 3 and its end — so with all of them in one ascending list T the number p of
+    // thresholds <= m is 4 * (combination position) + quarter.  `lut` gives, for each 2^16-wide bucket of m, how many
+    // thresholds lie at or below the bucket's first draw; the at most ONE that lies inside the bucket is compared exactly.
+    uint32_t T[kSlipThresholds]; // ascending, 0xFFFFFFFF beyond the 4 * nb real ones
+    uint8_t lut[kSlipBuckets];
+    bool lut_ok;                 // swar_ok, T ascending, and no bucket holds two thresholds (needs s^2 / 16 and (1 - s)^2 / 4 >= 2^-14:
+                                 // slips within about [0.032, 0.984]; the others compare threshold by threshold)
 };
 
 inline SlipTables build_slip_tables(double slip_prob) {
@@ -110,6 +121,20 @@ inline SlipTables build_slip_tables(double slip_prob) {
     bool mid = true;
     for (uint32_t i = 0; i < T.nb; ++i) mid = mid && T.sub[i].x == T.sub[i].z;
     T.swar_ok = T.slip_int == 1u && consecutive && mid;
+    // the table form
+    for (int j = 0; j < kSlipThresholds; ++j) T.T[j] = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < T.nb && i < 9; ++i) { T.T[4 * i] = T.sub[i].y; T.T[4 * i + 1] = T.sub[i].z; T.T[4 * i + 2] = T.sub[i].w; T.T[4 * i + 3] = T.CB[i]; }
+    bool lut_ok = T.swar_ok;
+    for (uint32_t j = 1; j < 4 * T.nb; ++j) lut_ok = lut_ok && T.T[j - 1] <= T.T[j];
+    constexpr int shift = 30 - kSlipBucketBits;
+    for (int b = 0; b < kSlipBuckets; ++b) {
+        const uint32_t lo = (uint32_t)b << shift, hi = lo + (1u << shift);
+        uint32_t below = 0, inside = 0;
+        for (uint32_t j = 0; j < 4 * T.nb; ++j) { if (T.T[j] <= lo) ++below; else if (T.T[j] < hi) ++inside; }
+        T.lut[b] = (uint8_t)below;
+        if (inside > 1u) lut_ok = false;
+    }
+    T.lut_ok = lut_ok;
     return T;
 }
 

@@ -26,6 +26,7 @@ def host(tmp_path_factory):
     L.swar_step_host.argtypes = [C.c_int] * 6 + [C.c_long] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 9
     L.swar_draws_host.argtypes = [C.c_void_p, C.c_void_p]
     L.swar_slip_tables.argtypes = [C.c_double] + [C.c_void_p] * 4
+    L.swar_set_slip_select.argtypes = [C.c_int]
     L.swar_reset_host.restype = C.c_int
     L.swar_reset_host.argtypes = [C.c_int, C.c_int, C.c_long] + [C.c_void_p] * 9
     return L
@@ -57,6 +58,8 @@ def _run_swar(L, w, h, max_steps, autoreset, general, full, st, t, need, aa, ab,
                           _p(np.ascontiguousarray(words, np.uint32)), float(slip),
                           _p(out["obs"]), _p(out["final_obs"]), _p(out["reward"]), _p(out["terminated"]),
                           _p(out["truncated"]), _p(out["prob_code"]), _p(out["finished"]), _p(out["frozen"]), _p(out["bad"]))
+    if rc == -4:
+        pytest.skip("slip %r has no bucket table (its thresholds crowd a bucket): the kernels compare one by one" % slip)
     assert rc == 0
     out["reward"] = out["reward"].view(np.int8)
     out["state"] = (ra, ca, rb, cb, ps, tt)
@@ -215,9 +218,19 @@ def _slip_words(slip, n, rng):
     return ((m << 2) | rng.integers(0, 4, size=n)).astype(np.uint32)
 
 
+@pytest.fixture(params=["one_by_one", "table"])
+def selection(request, host):
+    """both forms of the per-lane slip selection the kernels have: the thresholds compared one by one (slip_select4) and the
+    bucket table over the draw's top bits + three exact compares (slip_select4_lut, what the rollout takes whenever the
+    slip's thresholds do not crowd a bucket)"""
+    host.swar_set_slip_select(1 if request.param == "one_by_one" else 2)
+    yield request.param
+    host.swar_set_slip_select(1)
+
+
 @pytest.mark.parametrize("w,h,slip", [(5, 4, 0.2), (5, 4, 0.5), (5, 4, 1.0), (5, 4, 0.3), (5, 4, 0.05), (7, 5, 0.3), (11, 7, 0.2),
                                       (5, 4, 0.1), (5, 4, 0.9), (5, 4, 0.15), (6, 4, 0.4), (5, 4, 2.0 / 3.0), (5, 4, 0.6)])
-def test_slip_step_every_tuple_and_action_with_draws_on_every_threshold(host, w, h, slip):
+def test_slip_step_every_tuple_and_action_with_draws_on_every_threshold(host, selection, w, h, slip):
     rng = np.random.default_rng(int(slip * 100) + w)
     o = Oracle(w, h, slip, n=1)
     tup = _tuples(o, [1, 2])
@@ -256,7 +269,7 @@ def test_integer_slip_thresholds_are_the_float64_cumsum_for_every_list_shape(hos
     thresholds needed a float64 walk inside the kernels under round 2's u = m * 2^-30, are plain integer handles now."""
     from fractions import Fraction
     import math
-    cb = np.zeros(9, np.uint32); sub = np.zeros(36, np.uint32); flags = np.zeros(4, np.uint32); w4 = np.zeros(4, np.float64)
+    cb = np.zeros(9, np.uint32); sub = np.zeros(36, np.uint32); flags = np.zeros(8, np.uint32); w4 = np.zeros(4, np.float64)
     host.swar_slip_tables(float(slip), _p(cb), _p(sub), _p(flags), _p(w4))
     assert flags[0] == 1 and flags[1] == 1, "slip %r should take the integer decision on the byte-parallel path" % slip
     s = slip
@@ -281,6 +294,13 @@ def test_integer_slip_thresholds_are_the_float64_cumsum_for_every_list_shape(hos
             if n == 4:
                 assert ends[:3] == [int(x) for x in sub[4 * i + 1:4 * i + 4]]
     assert cb[len(active) - 1] == 2 ** 30                              # no draw falls beyond the last entry
+    # the table form exists unless two of the 4 * nb thresholds share one 2^16-wide bucket of the draw (tiny s: the four
+    # s^2 / 4 combinations; s near 1: the (1 - s)^2 one)
+    thr = np.sort(np.concatenate([np.stack([sub[1::4], sub[2::4], sub[3::4], cb], 1)[:len(active)].ravel()]).astype(np.int64))
+    inside = np.bincount((thr[(thr > 0) & (thr < 2 ** 30) & (thr % 2 ** 16 != 0)] >> 16), minlength=16384)
+    assert bool(flags[4]) == bool(inside.max() <= 1), (slip, flags[4], inside.max())
+    if slip in (0.1, 0.2, 0.5, 1.0 / 3.0):
+        assert flags[4] == 1
 
 
 def test_eight_ticks_share_one_block_at_slip_zero(host):

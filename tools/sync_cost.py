@@ -47,3 +47,24 @@ for name, fn in (("torch.cuda.synchronize()", torch.cuda.synchronize), ("nothing
         launch.append(t1 - t0); wait.append(t2 - t1); ts.append(t3 - t2)
     print("%-12s %-44s launch call %.1f us, to stamp (+ marker) %.1f us, closing sync median %.1f us" % (
         "empty graph", name, np.median(launch) * 1e6, np.median(wait) * 1e6, np.median(ts) * 1e6))
+
+# does it matter what the LAST packet of the stream is?  the same 20-launch replay, then one more stamp enqueued eagerly
+# (a plain kernel launch carries its own completion signal), watched, then the synchronisation
+b = SoccerBatch(N, 5, 4, 0.0, seed=0, autoreset=True, step_stats=False)
+b.reset(); b.sync()
+b.graph_begin(); b.timer_start()
+for k in range(K):
+    b.step_plain(acts[k, 0], acts[k, 1], obs[k], rew[k], term[k], trunc[k])
+b.timer_mark(); g = b.graph_end()
+b.graph_launch(g, 1); b.timer_read(); torch.cuda.synchronize()
+for name, fn in (("torch.cuda.synchronize()", torch.cuda.synchronize), ("soccer_sync", b.sync)):
+    ts, launch, wait = [], [], []
+    for _ in range(30):
+        torch.cuda.synchronize(); time.sleep(0.0005); b.stamps_clear(5, 1)
+        t0 = time.perf_counter(); b.graph_launch(g, 1); b.stamp(5); t1 = time.perf_counter()
+        while int(b.stamps(5, 1)[0][0]) == 0:
+            pass
+        t2 = time.perf_counter(); fn(); t3 = time.perf_counter()
+        launch.append(t1 - t0); wait.append(t2 - t1); ts.append(t3 - t2)
+    print("%-12s %-44s launch calls %.1f us, to eager stamp %.1f us, closing sync median %.1f us (total %.1f)" % (
+        "graph+eager", name, np.median(launch) * 1e6, np.median(wait) * 1e6, np.median(ts) * 1e6, np.median(np.array(launch) + np.array(wait) + np.array(ts)) * 1e6))
