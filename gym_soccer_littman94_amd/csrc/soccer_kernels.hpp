@@ -970,6 +970,9 @@ struct SwarParams {
 // SLIP: handles with slip_prob > 0 whose integer slip decision is the reference's for every draw (SlipTables::swar_ok):
 // each lane counts the integer cumulative weights and its combination's quarter points below its draw (the threshold rows
 // are gathered while the state loads are still in flight: they depend on the random word only), the rest stays byte-parallel.
+// (The rollout's bucket-table selection does not pay here: gathered from global memory, the 16 KB byte table + threshold list
+// is two dependent L2 round trips — 5.15 us per launch, the same as comparing one by one — and a 64 KB table with the
+// candidate inlined, one gather, thrashes the 16 KB L1: 6.05 us.)
 // Without SLIP the thread's block is the one of tick >> 3 and the lanes' draws are this tick's nibbles (swar::rand_nibble).
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the observation of
 // the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
