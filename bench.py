@@ -239,19 +239,28 @@ def main():
     for k in range(W):
         enqueue(k % K)
     b.sync()
-    graph = None
+    graph = graph_s = None
     warm_replays, first_ms = 0, None
     if args.mode == "graph" and KG > 0:
+        # the graph that is timed: exactly the K launches, nothing else
         b.graph_begin()
-        b.timer_start()               # the two event records are nodes of the graph: they bracket the K launches on the
-        for k in range(KG):           # device, so launch_us carries no share of the replay's start-up latency
+        for k in range(KG):
+            enqueue(k)
+        graph = b.graph_end()         # instantiated and uploaded (hipGraphUpload)
+        # its twin for the device-side figures: the same launches between two clock stamps (each stamp is a one-thread kernel
+        # of its own — ~1.9 us of device time that does not belong in a region that times K steps, which is why the timed graph
+        # has none); replayed after the timed region under the same conditions
+        b.graph_begin()
+        b.timer_start()
+        for k in range(KG):
             enqueue(k)
         b.timer_mark()
-        graph = b.graph_end()         # instantiated and uploaded (hipGraphUpload)
-        # One untimed replay of the graph that is about to be timed (the workload is stationary: advancing the state
-        # changes nothing), bracketed by the same event pair: the timed region then pays none of the path's one-off costs.
-        b.graph_launch(graph, 1); first_ms = b.timer_read()
-        warm_replays = 1
+        graph_s = b.graph_end()
+        # One untimed replay of each (the workload is stationary: advancing the state changes nothing): the timed region
+        # then pays none of the path's one-off costs.
+        b.graph_launch(graph, 1)
+        b.graph_launch(graph_s, 1); first_ms = b.timer_read()
+        warm_replays = 2
         b.sync()
     b.reset_stats()
     eager_args = None
@@ -261,22 +270,19 @@ def main():
 
     def barrier():
         # ONE host synchronisation: hipDeviceSynchronize covers the handle's own (non-blocking) stream as well as torch's.
-        # In the timed region it is called after soccer_timer_read has already seen the closing stamp, i.e. on an idle device.
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
-    t_enq = t_seen = None
+    t_enq = None
+    ev_ms = None
     if graph is not None:
-        b.graph_launch(graph, 1); t_enq = time.perf_counter()
-        ev_ms = b.timer_read(); t_seen = time.perf_counter()
-        if KG < K:                  # odd K: one eager launch on top of the captured even number
-            b.timer_start()
-            for k in range(KG, K):
-                enqueue(k)
-            ev_ms += b.timer_stop()
+        b.graph_launch(graph, 1)
+        for k in range(KG, K):      # odd K: one eager launch on top of the captured even number
+            enqueue(k)
+        t_enq = time.perf_counter()
     else:
         b.timer_start()
         step, chk, h = b.lib.batched_step, b._check, b.h
@@ -285,6 +291,15 @@ def main():
         ev_ms = b.timer_stop()
     barrier()
     wall = time.perf_counter() - t0
+    if graph is not None:
+        # device-side duration of the same K launches: the stamped twin, replayed after an idle barrier like the timed
+        # region was, three times; the median, scaled to K when K is odd
+        reps = []
+        for _ in range(3):
+            barrier()
+            b.graph_launch(graph_s, 1); reps.append(b.timer_read())
+        barrier()
+        ev_ms = sorted(reps)[1] * K / KG
     per_rank = None
     if world > 1:
         # every rank's own clocks, so that a scaling line shows rank skew; the job's time is the slowest rank's
@@ -374,7 +389,7 @@ def main():
                    "bytes_per_env_step": bytes_per,
                    "achieved_GBps": bytes_per * world * N * T / (r_ms * 1e-3) / 1e9,
                    "frac_of_hbm_peak": bytes_per * world * N * T / (r_ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world),
-                   "kernel": "soccer::rollout_swar_kernel<0, %s, 1>" % ("true" if args.slip else "false")}
+                   "kernel": "soccer::rollout_swar_kernel<0, %s, 1>" % ("1|2" if args.slip else "0")}   # as rocprofv3 prints it
 
     # ---- optional: BASELINE config 5 shape — both players sample from [nS, 5] mixed policies in-kernel --
     selfplay = None
@@ -479,12 +494,12 @@ def main():
                          "achieved_device": achieved_dev, "frac_device": achieved_dev / HBM_PEAK_GBPS,
                          "launch_us": launch_s * 1e6, "device_region_us": ev_ms * 1e3,
                          "host_overhead_us": wall * 1e6 - ev_ms * 1e3,
-                         # where the host's share of the timed region goes (graph mode, one rank): the hipGraphLaunch call,
-                         # from its return to the closing stamp being seen (device region + whatever start-up latency the
-                         # replay had left), and the one synchronisation that closes the region
+                         # where the host's share of the timed region goes (graph mode, one rank): the hipGraphLaunch call, and
+                         # from its return to the return of the one synchronisation that closes the region
                          "host_timeline_us": None if t_enq is None or world > 1 else {
-                             "graph_launch_call": (t_enq - t0) * 1e6, "launch_return_to_stamp_seen": (t_seen - t_enq) * 1e6,
-                             "closing_sync": (t0 + wall - t_seen) * 1e6},
+                             "graph_launch_call": (t_enq - t0) * 1e6, "launch_return_to_synchronised": (t0 + wall - t_enq) * 1e6},
+                         "device_figures_from": "a stamped twin of the timed graph (the same K launches between two device clock stamps), "
+                                                "median of three replays after the timed region" if graph is not None else "HIP events around the eager launches",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N},
             "episodes": {"hist_minus1_0_plus1": [int(x) for x in hist],
                          "gathered_last_returns": int(gathered.numel()), "gather_allreduce_ms": gather_ms,
@@ -505,7 +520,7 @@ def main():
         out["reference_python"] = REFERENCE_PYTHON
         print(json.dumps(out))
     if graph is not None:
-        b.graph_destroy(graph)
+        b.graph_destroy(graph); b.graph_destroy(graph_s)
     b.close()
     if world > 1:
         dist.destroy_process_group()
