@@ -212,7 +212,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
 
     from gym_soccer_littman94_amd import SoccerBatch
-    from gym_soccer_littman94_amd.distributed import gather_lane_values, reduce_histogram, shard_range
+    from gym_soccer_littman94_amd.distributed import gather_lane_values, gather_rank_values, reduce_histogram, shard_range
     N, K, W = args.lanes, args.steps, args.warmup
     lane_lo, lane_hi = shard_range(world * N, rank, world)      # contiguous global lane ids of this rank
     assert lane_hi - lane_lo == N
@@ -303,10 +303,7 @@ def main():
     per_rank = None
     if world > 1:
         # every rank's own clocks, so that a scaling line shows rank skew; the job's time is the slowest rank's
-        mine = torch.tensor([wall, ev_ms], dtype=torch.float64, device=cdev)
-        allr = torch.empty((world, 2), dtype=torch.float64, device=cdev)
-        dist.all_gather_into_tensor(allr, mine)
-        allr = allr.cpu()
+        allr = gather_rank_values([wall, ev_ms], device=cdev)
         per_rank = [{"rank": r, "wall_us": float(allr[r, 0]) * 1e6, "launch_us": float(allr[r, 1]) * 1e3 / K} for r in range(world)]
         wall, ev_ms = float(allr[:, 0].max()), float(allr[:, 1].max())
 

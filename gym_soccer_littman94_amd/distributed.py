@@ -55,3 +55,15 @@ def reduce_histogram(hist, device=None, group=None):
     t = torch.tensor([int(x) for x in hist], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return [int(x) for x in t.cpu()]
+
+
+def gather_rank_values(values, device=None, group=None):
+    """Every rank's small vector of float64 values (its own clocks, say) -> a [world, len(values)] CPU tensor on every
+    rank.  One all_gather_into_tensor into a FLAT buffer (the form both gloo and RCCL accept)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    flat = torch.empty(world * mine.numel(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    return flat.cpu().view(world, mine.numel())

@@ -35,16 +35,17 @@ def _worker(rank, world, port, total, out_dir):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from gym_soccer_littman94_amd.distributed import gather_lane_values, reduce_histogram, shard_range
+    from gym_soccer_littman94_amd.distributed import gather_lane_values, gather_rank_values, reduce_histogram, shard_range
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     lo, hi = shard_range(total, rank, world)
     last, obs, hist = _run_shard(lo, hi, 130, 9, 0.2)
     g_last = gather_lane_values(torch.from_numpy(last), total)
     g_obs = gather_lane_values(torch.from_numpy(obs.astype(np.int32)), total)
     g_hist = reduce_histogram(hist)
+    g_clk = gather_rank_values([100.0 + rank, 0.5 * rank])          # bench.py's per_rank clocks
     dist.barrier()
     if rank == 0:
-        np.savez(os.path.join(out_dir, "gathered.npz"), last=g_last.numpy(), obs=g_obs.numpy(), hist=np.array(g_hist))
+        np.savez(os.path.join(out_dir, "gathered.npz"), last=g_last.numpy(), obs=g_obs.numpy(), hist=np.array(g_hist), clk=g_clk.numpy())
     dist.destroy_process_group()
 
 
@@ -68,4 +69,5 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path):
     np.testing.assert_array_equal(g["last"], last)
     np.testing.assert_array_equal(g["obs"], obs)
     np.testing.assert_array_equal(g["hist"], hist)
+    np.testing.assert_array_equal(g["clk"], [[100.0, 0.0], [101.0, 0.5]])
     assert hist.sum() > total

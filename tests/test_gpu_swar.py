@@ -398,8 +398,10 @@ def test_vector_env_strict_mode_reports_bad_device_actions():
     v.step({"player_a": bad, "player_b": ok})
     torch.cuda.synchronize()
     with pytest.raises(AssertionError, match="actions must be in 0..4"):
-        v.step({"player_a": ok, "player_b": ok})
-    v.step({"player_a": ok, "player_b": ok})                 # the flag was cleared with the report
+        for _ in range(4):                                   # the host-mapped flags are looked at every fourth step
+            v.step({"player_a": ok, "player_b": ok})
+    for _ in range(8):
+        v.step({"player_a": ok, "player_b": ok})             # the flag was cleared with the report
     v.close()
     vn = VectorSoccerEnv(64, seed=0)
     vn.reset()
