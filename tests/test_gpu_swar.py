@@ -500,3 +500,33 @@ def test_lean_device_vector_env_returns_what_the_full_one_does(slip):
     with pytest.raises(AssertionError):
         lean.episode_histogram()
     full.close(); lean.close()
+
+
+@pytest.mark.parametrize("slip", [0.0, 0.2])
+def test_rollout_at_every_block_alignment_and_length(slip):
+    """At slip 0 eight ticks share a Philox block, and the rollout fetches its action streams a block (8 ticks) ahead: both
+    are steered by tick & 7.  Every alignment of the first tick (0..8) x lengths around the block size, the trajectories and
+    the state against the oracle — and against T single steps from the same state (rollout step j = the j-th batched_step)."""
+    n = 1024
+    rng = np.random.default_rng(12)
+    acts = rng.integers(0, 5, size=(20, 2, n), dtype=np.int8)
+    b = SoccerBatch(n, 5, 4, slip, seed=77, autoreset=True); o = Oracle(5, 4, slip, n=n, seed=77, autoreset=True)
+    b2 = SoccerBatch(n, 5, 4, slip, seed=77, autoreset=True)
+    b.reset(); o.reset(); b2.reset()
+    A2 = b2.alloc(n, np.int8); B2 = b2.alloc(n, np.int8); O2 = b2.alloc(n, np.uint16)
+    for tick0 in range(0, 9):
+        for T in (1, 2, 7, 8, 9, 15, 16, 17, 20):
+            t0 = 1000 * 8 + tick0
+            b._check(b.lib.soccer_set_tick(b.h, t0)); b2._check(b2.lib.soccer_set_tick(b2.h, t0)); o.tick = t0
+            st = b.get_state()
+            b2.set_state(st["row_a"], st["col_a"], st["row_b"], st["col_b"], st["poss"], t=st["t"], needs_reset=st["needs_reset"])
+            _rollout_vs_oracle(b, o, acts[:T], T, n)
+            for k in range(T):
+                A2.upload(acts[k, 0]); B2.upload(acts[k, 1])
+                b2.step(A2, B2, obs=O2)
+            s1, s2 = b.get_state(), b2.get_state()
+            for key in s1:
+                np.testing.assert_array_equal(s1[key], s2[key], err_msg="%s after tick0 %d T %d" % (key, tick0, T))
+            assert b.tick == t0 + T == b2.tick
+            b.reset_stats(); o.hist[:] = 0
+    b.close(); b2.close()
