@@ -1290,7 +1290,7 @@ extern "C" int soccer_timer_read(soccer_handle* h, float* elapsed_ms) {
             // The closing stamp was zeroed before the (single) replay was enqueued and its kernel writes it to host-mapped
             // memory: watching that word costs no runtime call at all — the host sees the end of the region ~1 us after
             // the device reaches it.  (The runtime's own completion signal of the replay arrives ~13 us after the last
-            // kernel on an MI355X — the write-back of the dirty L2 lines and the signal path, tools/sync_cost.py — whether
+            // kernel on an MI355X — the write-back of the dirty L2 lines and the signal path, tools/labs/sync_cost.py — whether
             // one waits for it in hipStreamSynchronize, in hipDeviceSynchronize or by polling an event recorded behind
             // the replay; a host that only needs the device time does not have to.)
             const auto t_start = std::chrono::steady_clock::now();

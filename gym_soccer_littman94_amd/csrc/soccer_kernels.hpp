@@ -124,7 +124,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 // Callers pass `tick >> 3` for the step/reset block of a slip_prob == 0 handle (one block serves eight ticks).
 __device__ __forceinline__ Philox4 lane_block(const KernelParams& P, unsigned long long q,
                                               unsigned long long tick, uint32_t purpose) {
-#ifdef SOCCER_LAB_NO_PHILOX     // tools/kernel_lab.hip ablation build only
+#ifdef SOCCER_LAB_NO_PHILOX     // tools/labs/kernel_lab.hip ablation build only
     return Philox4{{(uint32_t)q * 2654435761u, (uint32_t)tick, (uint32_t)q ^ 0x9E3779B9u, purpose}};
 #endif
     return philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)tick,
@@ -232,7 +232,7 @@ struct Resolved { uint32_t kind, nA, nB; };
 
 // the cell a player reaches with one move (_next_cell :364-373, via the move/bounds table)
 __device__ __forceinline__ uint32_t moved(const Tables& T, const KernelParams& P, uint32_t pos, uint32_t has_ball, uint32_t mv) {
-#ifdef SOCCER_LAB_NO_GATHER     // tools/kernel_lab.hip ablation build only
+#ifdef SOCCER_LAB_NO_GATHER     // tools/labs/kernel_lab.hip ablation build only
     return pos + (mv == 3u ? 0x00010001u : 0u) * (has_ball & 1u);
 #endif
     return T.nc[mad24(has_ball, (uint32_t)P.HW5, mad24(cell_of(pos), 5u, mv))];
@@ -660,7 +660,7 @@ __device__ __forceinline__ void lane_words(const KernelParams& P, unsigned long 
 // =================================================================================================
 // Each thread owns the 4 consecutive lanes [4g, 4g+4) and walks them in a ROLLED loop: the code of one
 // lane step exists once, so a launch — which starts with a cold instruction cache — fetches ~4x less
-// code than an unrolled body (measured: 12.8 -> 10.2 us per launch at 2^20 lanes, tools/kernel_lab).
+// code than an unrolled body (measured: 12.8 -> 10.2 us per launch at 2^20 lanes, tools/labs/kernel_lab).
 // Bytes are peeled off the packed input dwords by shifting and results are shifted into packed output
 // dwords with v_alignbyte, so no per-lane register arrays are needed.  The rule tables are read
 // straight from global memory (4.3 KB, L1/L2 resident): with 3 lookups per lane a per-workgroup LDS
@@ -917,7 +917,7 @@ __device__ __forceinline__ void hot_group(const KernelParams& P, const StepIO& I
 // (the hot path always starts at lane 0 of the handle):
 // the library is built with -mllvm -amdgpu-kernarg-preload-count=14, so they arrive in SGPRs at wave launch
 // and the nine data loads are issued without first waiting for a scalar load of the kernarg segment
-// (-0.3 .. -0.6 us per launch, tools/pipeline_lab.hip); the rest of P is fetched while they are in flight.
+// (-0.3 .. -0.6 us per launch, tools/labs/pipeline_lab.hip); the rest of P is fetched while they are in flight.
 template <bool SLIP, bool INT_ONLY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsigned long long state_stride,
                                                           const int8_t* act_a, const int8_t* act_b,
@@ -963,7 +963,7 @@ struct SwarParams {
 //   1  + reward_a_f32 / reward_b_f32 / finished / last_return: what a gym-style loop reads every step, without the `info`
 //      extras (VectorSoccerEnv(io="device", info=False): 27 B per env-step when the int8 reward stream is left out)
 //   2  + final_obs / prob_code and, when Q.hist is set, the episode histogram (VectorSoccerEnv's info; 31 B)
-// Launch shape (tools/swar_sweep.sh, profiles/r02_sweep.md): one 4-lane group per thread with non-temporal dword
+// Launch shape (tools/labs/swar_sweep.sh, profiles/r02_sweep.md): one 4-lane group per thread with non-temporal dword
 // accesses measured best; 8 or 16 lanes per thread (dwordx2 / dwordx4), plain or write-through stores and 512-thread
 // workgroups were all equal or slower, and an instantiation without the frozen-lane / goal-tuple code was not faster
 // (the kernel is bound by launch + memory latency, not by vector issue any more).
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel_swar(const ResetSwar R) {
 // =================================================================================================
 // Inputs arrive BY VALUE as kernel arguments and the results leave as ONE 16-byte store to a host-mapped
 // record the host polls: the GPU reads no host memory and the host never enters a stream synchronisation
-// (tools/latency_lab.hip: 7.9 us for launch + kernel-written flag + poll against 12.6 us for launch +
+// (tools/labs/latency_lab.hip: 7.9 us for launch + kernel-written flag + poll against 12.6 us for launch +
 // hipStreamSynchronize).  The lane's resident state streams are updated too.
 struct ScalarIO {
     uint32_t pos;       // row_a | col_a << 8 | row_b << 16 | col_b << 24
@@ -1497,7 +1497,7 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             }
             rnd = swar::rand_pair(C.isd_shift, t, p0);
             // odd tick: the pair is used up.  The empty asm keeps this a (scalar) branch around three moves; as selects it
-            // was three v_cndmask_b32 every step, each several times the cost of a move (tools/valu_rate_lab.hip).
+            // was three v_cndmask_b32 every step, each several times the cost of a move (tools/labs/valu_rate_lab.hip).
             if (t & 1u) { asm volatile(""); p0 = p1; p1 = p2; p2 = p3; }
         }
         swar::step4<GENERAL, false, SLIP, GEO, TRUSTED>(C, S, a4, b4, sa, sb, cls4, rnd, o);

@@ -58,7 +58,7 @@ SOCCER_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
 }
 // v_bfi_b32: bits of x where m is set, bits of y elsewhere
 // (as v_bitop3_b32, truth table 0xca: with register operands it issues like a plain logic op, v_bfi_b32 does not —
-// tools/valu_rate_lab.hip)
+// tools/labs/valu_rate_lab.hip)
 SOCCER_HD uint32_t bfi(uint32_t m, uint32_t x, uint32_t y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_bitop3_b32(m, x, y, 0xca);

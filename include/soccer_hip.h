@@ -219,7 +219,7 @@ int soccer_set_policy(soccer_handle* h, int32_t player, const int8_t* policy_hos
 /* For handles with n_lanes == 1.  The current tuple, the actions and the uniform go in BY VALUE (kernel
  * arguments), the result comes back through a host-mapped record that the kernel writes with one 16-byte
  * store and the call polls: the GPU reads no host memory and the host enters no stream synchronisation
- * (~2x lower latency than batched_step_host on a mapped handle, tools/latency_lab.hip).
+ * (~2x lower latency than batched_step_host on a mapped handle, tools/labs/latency_lab.hip).
  * soccer_step_scalar: in  = row_a..col_b, poss, t, act_a, act_b (ignored for a side with a fixed policy),
  *                           u_step, u_reset (used only with SOCCER_F_AUTORESET);
  *                     out = the next tuple / poss / t / needs_reset in the same fields, obs, reward (player A's),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the driver's bench shape (--steps 20 --warmup 5) under different HIP wait settings.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 pick() { python3 -c "
 import sys, json
 for l in sys.stdin:

@@ -3,7 +3,7 @@
 //   empty      nothing                                    -> launch + dependent-kernel boundary
 //   copy       8 loads, 10 stores, one xor per dword      -> + the 19 B/lane round trip
 //   copy+rng   + the Philox block of the thread's 4 lanes -> + the vector work that no rule needs
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Igym_soccer_littman94_amd/csrc -o build/floor_lab tools/floor_lab.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Igym_soccer_littman94_amd/csrc -o build/floor_lab tools/labs/floor_lab.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

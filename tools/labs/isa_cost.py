@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Weighted vector-issue cost of an asm fragment (stdin or file), using the issue classes tools/valu_rate_lab.hip
+"""Weighted vector-issue cost of an asm fragment (stdin or file), using the issue classes tools/labs/valu_rate_lab.hip
 measured on gfx950 with DEPENDENT CHAINS of one instruction: plain VOP1/VOP2 integer ops on VGPR operands ~1 unit,
 v_bitop3_b32 on VGPRs ~1.4, everything else (shifts, multiplies, v_perm, v_bfi, packed ops, VOP3 forms, any vector op
 reading an SGPR) ~2.
 CAVEAT: a rough guide only.  The model did NOT predict kernel-level results in round 2: moving the rollout loop's
 constants and Philox keys from SGPRs into VGPRs cut the modelled cost by 8 % (335 -> 307 units) but measured +2 % on the
 fused rollout and +-0 on the self-play rollout (profiles/r02_e_summary.md).  Trust an A/B of the real kernel
-(tools/lib_ab.sh), not these weights."""
+(tools/labs/lib_ab.sh), not these weights."""
 import re, sys, collections
 FAST = {'v_xor_b32', 'v_add_u32', 'v_sub_u32', 'v_subrev_u32', 'v_and_b32', 'v_or_b32', 'v_mov_b32', 'v_not_b32'}
 src = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()

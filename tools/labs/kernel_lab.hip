@@ -1,5 +1,5 @@
 // kernel_lab.hip — ablation harness for step_kernel at N = 2^20 (diagnostic; not shipped).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I gym_soccer_littman94_amd/csrc tools/kernel_lab.hip -o build/kernel_lab
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I gym_soccer_littman94_amd/csrc tools/labs/kernel_lab.hip -o build/kernel_lab
 // Times interleaved variants in one process with HIP events (cdna_hip_programming.md §5.4 rule 24).
 #include <hip/hip_runtime.h>
 #include <cstdio>

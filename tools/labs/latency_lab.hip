@@ -1,7 +1,7 @@
 // Where do the ~45 us of a 1-lane facade step go?  Completion mechanisms for a tiny kernel on host-mapped
 // memory, measured from C++ (no Python): stream sync, event-query spin, stream write-value + poll, and a
 // flag the kernel itself writes to mapped memory + poll.  Plus the C-ABI staged step on a mapped handle.
-//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/latency_lab.hip -o build/latency_lab \
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/labs/latency_lab.hip -o build/latency_lab \
 //         -Lgym_soccer_littman94_amd -lsoccer_hip -Wl,-rpath,$PWD/gym_soccer_littman94_amd
 #include <hip/hip_runtime.h>
 #include <chrono>

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: A/B of library variants built into build/lib_<name>.so (each is copied over the package's
-# libsoccer_hip.so of this scratch copy, then bench.py's step-only command runs).  Usage: tools/lib_ab.sh base prio1 ... [-- bench flags]
-cd "$(dirname "$0")/.."
+# libsoccer_hip.so of this scratch copy, then bench.py's step-only command runs).  Usage: tools/labs/lib_ab.sh base prio1 ... [-- bench flags]
+cd "$(dirname "$0")/../.."
 NAMES=(); EXTRA=()
 while [ $# -gt 0 ]; do if [ "$1" == "--" ]; then shift; EXTRA=("$@"); break; fi; NAMES+=("$1"); shift; done
 for rep in 1 2 3; do

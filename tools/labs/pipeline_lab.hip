@@ -3,7 +3,7 @@
 // of step k, nothing else.  Variant "chain": every workgroup waits on a per-workgroup counter its
 // predecessor publishes, and the launches carry hipExtAnyOrderLaunch (no barrier between the dispatches),
 // so step k+1's workgroups start while step k's tail is still running.  Every wait is bounded.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I gym_soccer_littman94_amd/csrc tools/pipeline_lab.hip -o build/pipeline_lab
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I gym_soccer_littman94_amd/csrc tools/labs/pipeline_lab.hip -o build/pipeline_lab
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdio>

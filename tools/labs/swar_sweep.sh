@@ -3,7 +3,7 @@
 # in commit 4aef6d3..f61d5bd's library and were removed once the sweep had picked the shipped shape.
 # A/B sweep of the byte-parallel step kernel's launch shape (run on the GPU box): lanes per thread (G x 4), store policy
 # (0 nt, 1 plain, 2 write-through), block size, steady-state vs general instantiation.  Prints HIP-event us per launch.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 run() {
   local tag="$1"; shift
   local out

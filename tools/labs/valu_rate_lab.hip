@@ -2,7 +2,7 @@
 // dependent chain  x = op(x, y, c); y = op(y, x, c)  (inline asm, so the instruction is exactly the one named), 16 pairs per
 // loop iteration; ticks (s_memtime) per instruction and wave, at 1 wave per SIMD (latency of a dependent issue) and at
 // 4 waves per SIMD (the occupancy of the step / rollout kernels: 1024 x 256 threads on 256 CUs — throughput).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build/valu_rate_lab tools/valu_rate_lab.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build/valu_rate_lab tools/labs/valu_rate_lab.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
