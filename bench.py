@@ -256,11 +256,14 @@ def main():
             enqueue(k)
         b.timer_mark()
         graph_s = b.graph_end()
-        # One untimed replay of each (the workload is stationary: advancing the state changes nothing): the timed region
-        # then pays none of the path's one-off costs.
-        b.graph_launch(graph, 1)
+        # Untimed replays (the workload is stationary: advancing the state changes nothing): the timed region then pays none
+        # of the path's one-off costs — three of the graph that is timed, each followed by a synchronisation like the timed
+        # one (a replay's first and second launch have been seen to cost the host 3x the usual hipGraphLaunch call), one of
+        # the twin.
+        for _ in range(3):
+            b.graph_launch(graph, 1); b.sync()
         b.graph_launch(graph_s, 1); first_ms = b.timer_read()
-        warm_replays = 2
+        warm_replays = 4
         b.sync()
     b.reset_stats()
     eager_args = None
