@@ -50,17 +50,20 @@ def cpu_baseline(lanes_total, slip, seconds):
         while time.perf_counter() < deadline[0]:
             o.step(acts[k % 64, 0], acts[k % 64, 1]); k += 1
         counts[i] = k
-    # calibrate on one thread for ~1 s so the sample is bounded, then run all threads
-    deadline[0] = time.perf_counter() + seconds
+    # one core first ("on 1 core and on all cores"), a quarter of the budget; then all threads
+    deadline[0] = time.perf_counter() + seconds * 0.25
+    t0 = time.perf_counter(); work(0); dt1 = time.perf_counter() - t0
+    one_core = counts[0] * per / dt1
+    deadline[0] = time.perf_counter() + seconds * 0.75
     t0 = time.perf_counter()
     ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
     for t in ts: t.start()
     for t in ts: t.join()
     dt = time.perf_counter() - t0
     steps = sum(counts) * per
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d threads x %d lanes x ~%d steps of the same uniform-random workload (%.1f s)"
-                      % (threads, per, counts[0], dt)}
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "value_1_core": one_core,
+            "sample": "%d threads x %d lanes x ~%d steps of the same uniform-random workload (%.1f s), after 1 thread alone for %.1f s"
+                      % (threads, per, counts[0], dt, dt1)}
 
 
 REFERENCE_PYTHON = {"value": 5.3e4, "unit": "env-steps/s", "cores": 1, "where": "build container (Xeon 2.1 GHz)",
