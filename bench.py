@@ -325,8 +325,8 @@ def main():
             enqueue(k); b.stamp(3 + k)
         gp = b.graph_end()
         for _ in range(3):
-            barrier(); b.stamps_clear(2, KG + 1)
-            b.graph_launch(gp, 1); barrier()
+            barrier()
+            b.graph_launch(gp, 1); barrier()          # (the slots are read after the synchronisation: no clearing needed)
         ticks, khz = b.stamps(2, KG + 1)
         d_us = np.diff(ticks.astype(np.int64)) / (khz * 1e-3)
         launch_profile = {"what": "device-clock deltas between stamps placed after every launch of one %d-launch replay "

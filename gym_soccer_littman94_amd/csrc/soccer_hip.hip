@@ -71,7 +71,8 @@ struct soccer_handle {
     uint32_t* d_slip_lut = nullptr;         // SlipTables::lut + T for the table form of the selection (when lut_ok)
     size_t hist_slots = kHistSlots;         // per-wave histogram slots (a power of two; see soccer_create)
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
-    bool stamp_poll = false;                // the closing stamp of the last soccer_graph_launch was cleared first: poll it
+    bool stamp_poll = false;                // soccer_timer_read may watch the closing stamp of the last soccer_graph_launch change ...
+    unsigned long long stamp_prev = 0;      // ... from this value (what the slot held when the replay was enqueued)
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
@@ -79,8 +80,13 @@ struct soccer_handle {
     std::string err;
 };
 
-// the handle's host-mapped block: dwords 0 / 1 the sticky misuse words, from byte 64 on SOCCER_STAMP_SLOTS u64 clock stamps
-constexpr size_t kMappedBytes = 64 + 8 * SOCCER_STAMP_SLOTS;
+// the handle's host-mapped block: dwords 0 / 1 the sticky misuse words, from byte 64 on SOCCER_STAMP_SLOTS u64 clock stamps,
+// ONE PER 64-BYTE LINE: a line the host has written or is polling costs the device a coherence round trip to write, and a
+// stamp kernel's store must complete before the next kernel starts — with the opening and the closing stamp of a captured
+// timer in one line (and the host clearing the closing one before every replay) the opening stamp's kernel boundary took
+// microseconds longer and inflated the region it opens
+constexpr size_t kStampStride = 8;          // in u64
+constexpr size_t kMappedBytes = 64 + 8 * kStampStride * SOCCER_STAMP_SLOTS;
 
 static thread_local std::string g_err;
 
@@ -1240,7 +1246,7 @@ extern "C" int soccer_stamp(soccer_handle* h, int32_t slot) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (slot < 0 || slot >= SOCCER_STAMP_SLOTS) return fail(h, SOCCER_E_INVALID, "stamp slot %d out of range (0..%d)", slot, SOCCER_STAMP_SLOTS - 1);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, h->stream, stamp_dev(h) + slot);
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, h->stream, stamp_dev(h) + kStampStride * slot);
     HIP_TRY(h, hipGetLastError());
     return SOCCER_OK;
 }
@@ -1248,7 +1254,7 @@ extern "C" int soccer_stamp(soccer_handle* h, int32_t slot) {
 extern "C" int soccer_stamps_clear(soccer_handle* h, int32_t first, int32_t count) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (first < 0 || count < 0 || first + count > SOCCER_STAMP_SLOTS) return fail(h, SOCCER_E_INVALID, "stamp range out of bounds");
-    for (int32_t i = 0; i < count; ++i) stamp_host(h)[first + i] = 0ull;
+    for (int32_t i = 0; i < count; ++i) stamp_host(h)[kStampStride * (first + i)] = 0ull;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     return SOCCER_OK;
 }
@@ -1256,7 +1262,7 @@ extern "C" int soccer_stamps_clear(soccer_handle* h, int32_t first, int32_t coun
 extern "C" int soccer_stamps_read(soccer_handle* h, int32_t first, int32_t count, uint64_t* ticks, int32_t* khz) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (first < 0 || count < 0 || first + count > SOCCER_STAMP_SLOTS || (count && !ticks)) return fail(h, SOCCER_E_INVALID, "stamp range out of bounds");
-    for (int32_t i = 0; i < count; ++i) ticks[i] = stamp_host(h)[first + i];
+    for (int32_t i = 0; i < count; ++i) ticks[i] = stamp_host(h)[kStampStride * (first + i)];
     if (khz) *khz = h->wall_clock_khz;
     return SOCCER_OK;
 }
@@ -1287,19 +1293,19 @@ extern "C" int soccer_timer_read(soccer_handle* h, float* elapsed_ms) {
     if (h->timer_stamped) {                 // the stamps of the last replay of a graph that captured start / mark
         volatile unsigned long long* st = stamp_host(h);
         if (h->stamp_poll) {
-            // The closing stamp was zeroed before the (single) replay was enqueued and its kernel writes it to host-mapped
-            // memory: watching that word costs no runtime call at all — the host sees the end of the region ~1 us after
-            // the device reaches it.  (The runtime's own completion signal of the replay arrives ~13 us after the last
+            // The closing stamp's kernel writes it to host-mapped memory and clock values only grow: watching that word
+            // change from what it held when the (single) replay was enqueued costs no runtime call at all — the host
+            // sees the end of the region ~1 us after the device reaches it — and the host never WRITES the stamp lines.  (The runtime's own completion signal of the replay arrives ~13 us after the last
             // kernel on an MI355X — the write-back of the dirty L2 lines and the signal path, tools/labs/sync_cost.py — whether
             // one waits for it in hipStreamSynchronize, in hipDeviceSynchronize or by polling an event recorded behind
             // the replay; a host that only needs the device time does not have to.)
             const auto t_start = std::chrono::steady_clock::now();
-            for (uint32_t spins = 0; st[1] == 0ull; ++spins) {
+            for (uint32_t spins = 0; st[kStampStride] == h->stamp_prev; ++spins) {
                 __builtin_ia32_pause();
                 if ((spins & 0xfffffu) == 0xfffffu) {                    // every few ms: has the stream died?
                     const hipError_t e = hipStreamQuery(h->stream);
                     if (e != hipSuccess && e != hipErrorNotReady) return fail(h, SOCCER_E_HIP, "soccer_timer_read: %s", hipGetErrorString(e));
-                    if (e == hipSuccess && st[1] == 0ull) return fail(h, SOCCER_E_STATE, "soccer_timer_read: the stream is idle but the closing stamp was never written");
+                    if (e == hipSuccess && st[kStampStride] == h->stamp_prev) return fail(h, SOCCER_E_STATE, "soccer_timer_read: the stream is idle but the closing stamp was never written");
                     if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
                         return fail(h, SOCCER_E_HIP, "soccer_timer_read: no closing stamp after 60 s");
                 }
@@ -1315,7 +1321,7 @@ extern "C" int soccer_timer_read(soccer_handle* h, float* elapsed_ms) {
             }
             (void)hipGetLastError();
         }
-        *elapsed_ms = (float)((double)(st[1] - st[0]) / (double)h->wall_clock_khz);
+        *elapsed_ms = (float)((double)(st[kStampStride] - st[0]) / (double)h->wall_clock_khz);
         return SOCCER_OK;
     }
     // poll instead of blocking: a blocked waiter is woken tens of microseconds after the event completes, which is
@@ -1386,9 +1392,10 @@ extern "C" int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t re
                                   sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
         h->tick_slot = g->start_slot;
     }
-    // one replay: zero the closing stamp first, so that soccer_timer_read can watch for it (several replays would each write it)
+    // one replay: remember what the closing stamp holds, so that soccer_timer_read can watch it change (several replays
+    // would each write it)
     h->stamp_poll = replays == 1 && g->stamped;
-    if (h->stamp_poll) { stamp_host(h)[1] = 0ull; std::atomic_thread_fence(std::memory_order_seq_cst); }
+    if (h->stamp_poll) h->stamp_prev = stamp_host(h)[kStampStride];
     for (int32_t r = 0; r < replays; ++r) HIP_TRY(h, hipGraphLaunch(g->exec, h->stream));
     h->tick += g->ticks * (uint64_t)(replays > 0 ? replays : 0);
     return SOCCER_OK;

@@ -351,9 +351,11 @@ int soccer_timer_stop(soccer_handle* h, float* elapsed_ms);    /* = mark + read 
 /* Device clock stamps.  soccer_stamp enqueues — or, inside a capture, records as a graph node — a one-thread kernel that
  * stores the device's constant-rate wall clock into slot `slot` of a host-mapped block; soccer_stamps_read copies slots
  * as they stand, WITHOUT synchronising (a slot reads 0 until its kernel has run, provided soccer_stamps_clear zeroed it
- * while nothing was writing it) and reports the clock rate.  A captured soccer_timer_start / _mark pair is stamps 0 and 1,
- * and after a single replay soccer_timer_read just watches slot 1 from the host: no runtime call sits between the end of
- * the region on the device and the host noticing it. */
+ * while nothing was writing it — but a line the host has just written costs the device a coherence round trip to write:
+ * prefer reading the slots after a synchronisation and never clearing them) and reports the clock rate.  Every slot has a
+ * 64-byte line of its own.  A captured soccer_timer_start / _mark pair is stamps 0 and 1, and after a single replay
+ * soccer_timer_read just watches slot 1 change from the host: no runtime call sits between the end of the region on the
+ * device and the host noticing it. */
 #define SOCCER_STAMP_SLOTS 256
 int soccer_stamp(soccer_handle* h, int32_t slot);
 int soccer_stamps_clear(soccer_handle* h, int32_t first, int32_t count);
