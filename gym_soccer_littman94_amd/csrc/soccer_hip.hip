@@ -551,9 +551,13 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                      a->terminated ? a->terminated + oo : nullptr, a->truncated ? a->truncated + oo : nullptr,
                      (long long)a->out_stride, a->return_sum, a->episode_count};
         // the byte-parallel rollout: every pitch that fits the byte arithmetic, slip 0 or an exact integer slip decision
-        const bool swar_roll = h->swar_ok && (!h->slip || h->slip_swar_ok) && (P.n & 3ull) == 0ull && ((P.lane_offset + P.first) & 3ull) == 0ull &&
+        // (a lane count that is not a multiple of 4: the byte-parallel kernel over the first n & ~3 lanes, the one to three
+        // left over through the per-lane kernel on the same ticks, like batched_step's ragged tail)
+        const bool swar_roll = h->swar_ok && (!h->slip || h->slip_swar_ok) && P.n >= 4ull && ((P.lane_offset + P.first) & 3ull) == 0ull &&
                                ok(4) && h->rollout_pref != 1;
+        const unsigned long long n_all = P.n, n4 = swar_roll ? (P.n & ~3ull) : 0ull;
         if (swar_roll) {
+            P.n = n4;
             const bool dyn = io.sample_actions || P.policy_a || P.policy_b;
             RolloutSwar RS{P.state, P.state_stride, P.first, P.n, P.lane_offset, P.tick_in, P.tick_out, P.hist, P.misuse,
                            P.policy_a, P.policy_b, P.key0, P.key1,
@@ -594,6 +598,12 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
 #undef LAUNCH_D
 #undef LAUNCH_S
 #undef LAUNCH_G
+            if (n4 < n_all) {
+                KernelParams Q = h->P;
+                Q.tick_in = P.tick_in; Q.tick_out = nullptr;      // the main launch publishes the tick
+                Q.first = n4; Q.n = n_all - n4;
+                launch_rollout<1>(h, Q, io);
+            }
         } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;
             case 4: launch_rollout<4>(h, P, io); break;

@@ -1294,17 +1294,17 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const KernelParams P, c
     HistAcc<false> hist; hist.init(P);
     const Tables T = stage_tables<LUT_LDS>(P, smem);
     const unsigned long long tick0 = *P.tick_in;
-    publish_tick(P, tick0, (unsigned long long)IO.n_steps);
-    const unsigned long long groups = (P.n + E - 1) / E;
+    if (P.tick_out) publish_tick(P, tick0, (unsigned long long)IO.n_steps);   // nullptr: the tail of a launch that already did
+    const unsigned long long groups = (P.n + E - 1) / E;        // the launch covers lanes [first, first + n) of the handle
     bool any_misuse = false;
     for (unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; g < groups;
          g += (unsigned long long)gridDim.x * kBlock) {
-        const unsigned long long i0 = g * E;
-        if (E == 1 || i0 + E <= P.n) {
+        const unsigned long long rel = g * E, i0 = P.first + rel;
+        if (E == 1 || rel + E <= P.n) {
             rollout_group<E, SLIP, DYN>(T, P, IO, i0, tick0, hist, any_misuse);
         } else {
-            for (unsigned long long i = i0; i < P.n; ++i)
-                rollout_group<1, SLIP, DYN>(T, P, IO, i, tick0, hist, any_misuse);
+            for (unsigned long long i = rel; i < P.n; ++i)
+                rollout_group<1, SLIP, DYN>(T, P, IO, P.first + i, tick0, hist, any_misuse);
         }
     }
     if (any_misuse) P.misuse[0] = 1u;

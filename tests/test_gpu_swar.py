@@ -530,3 +530,33 @@ def test_rollout_at_every_block_alignment_and_length(slip):
             assert b.tick == t0 + T == b2.tick
             b.reset_stats(); o.hist[:] = 0
     b.close(); b2.close()
+
+
+@pytest.mark.parametrize("slip", [0.0, 0.2])
+def test_rollout_with_a_lane_count_that_is_not_a_multiple_of_four(slip):
+    """n = 4 099 with row strides padded to 4 100: the byte-parallel rollout over the first 4 096 lanes, the last three through
+    the per-lane kernel on the same ticks — trajectories, state, per-lane sums and the histogram against the oracle."""
+    n, T, stride = 4099, 50, 4100
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    b = SoccerBatch(n, 5, 4, slip, seed=9, autoreset=True); o = Oracle(5, 4, slip, n=n, seed=9, autoreset=True)
+    b.reset(); o.reset()
+    pad = np.zeros((T, stride), np.int8)
+    pa = pad.copy(); pa[:, :n] = acts[:, 0]; pb = pad.copy(); pb[:, :n] = acts[:, 1]
+    A = b.alloc((T, stride), np.int8).upload(pa); B = b.alloc((T, stride), np.int8).upload(pb)
+    obs = b.alloc((T, stride), np.uint16).fill(0); rew = b.alloc((T, stride), np.int8).fill(0)
+    rs = b.alloc(n + 1, np.int32).fill(0)
+    b.rollout(T, A, B, act_stride=stride, obs=obs, reward=rew, out_stride=stride, return_sum=rs)
+    O, R = obs.download(), rew.download()
+    ret = np.zeros(n, np.int64)
+    for k in range(T):
+        c = o.step(acts[k, 0], acts[k, 1])
+        np.testing.assert_array_equal(O[k, :n], c["obs"], err_msg="obs %d" % k)
+        np.testing.assert_array_equal(R[k, :n], c["reward"], err_msg="reward %d" % k)
+        ret += c["reward"]
+    assert (O[:, n:] == 0).all() and (R[:, n:] == 0).all()           # nothing written beyond the batch
+    _state_equal(b, o)
+    np.testing.assert_array_equal(rs.download()[:n], ret)
+    np.testing.assert_array_equal(b.stats()[0], o.hist)
+    assert b.tick == o.tick
+    b.close()
