@@ -150,7 +150,8 @@ def _rollout_vs_oracle(b, o, acts, T, n, sample=False, mix=None):
     return ec.download(), eps
 
 
-@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (7, 5, 0.0), (9, 6, 0.0), (11, 7, 0.0), (5, 4, 0.2), (11, 7, 0.3), (6, 4, 1.0), (5, 4, 0.1)])
+@pytest.mark.parametrize("w,h,slip", [(5, 4, 0.0), (7, 5, 0.0), (9, 6, 0.0), (11, 7, 0.0), (5, 4, 0.2), (11, 7, 0.3), (6, 4, 1.0), (5, 4, 0.1),
+                                      (5, 4, 0.02), (5, 4, 0.999)])      # the last two: thresholds crowd a bucket, one-by-one selection
 def test_rollout_swar_streams_every_lane_every_step(w, h, slip):
     n, T = 8192, 120
     rng = np.random.default_rng(w + int(10 * slip))
@@ -560,3 +561,38 @@ def test_rollout_with_a_lane_count_that_is_not_a_multiple_of_four(slip):
     np.testing.assert_array_equal(b.stats()[0], o.hist)
     assert b.tick == o.tick
     b.close()
+
+
+def test_clock_stamps_and_the_captured_timer():
+    """soccer_stamp: device clock stamps in a host-mapped block, eagerly and as graph nodes; a captured timer_start / _mark
+    pair is stamps 0 / 1 and soccer_timer_read watches the closing one change.  Stamps grow along the stream, the captured
+    timer agrees with them, and an eager timer (HIP events) around the same launches is of the same size."""
+    n, K = 1 << 16, 8
+    b = SoccerBatch(n, 5, 4, 0.0, seed=1, autoreset=True, step_stats=False)
+    A = b.alloc(n, np.int8).fill(1); B = b.alloc(n, np.int8).fill(2)
+    obs = b.alloc(n, np.uint16); rew = b.alloc(n, np.int8); te = b.alloc(n, np.uint8); tr = b.alloc(n, np.uint8)
+    b.reset()
+    b.stamp(10)
+    for k in range(K):
+        b.step_plain(A, B, obs, rew, te, tr); b.stamp(11 + k)
+    b.sync()
+    t, khz = b.stamps(10, K + 1)
+    assert khz > 1000 and (np.diff(t.astype(np.int64)) > 0).all()
+    b.graph_begin(); b.timer_start()
+    for k in range(K):
+        b.step_plain(A, B, obs, rew, te, tr)
+    b.timer_mark(); g = b.graph_end()
+    for _ in range(3):
+        b.graph_launch(g, 1); ms = b.timer_read()
+        s01, _ = b.stamps(0, 2)
+        assert ms > 0 and abs(ms - (int(s01[1]) - int(s01[0])) / khz) < 1e-6
+    b.sync()
+    b.timer_start()
+    for k in range(K):
+        b.step_plain(A, B, obs, rew, te, tr)
+    eager_ms = b.timer_stop()
+    assert 0.2 * ms < eager_ms < 20 * ms
+    with pytest.raises(AssertionError):
+        b.stamp(256)
+    assert b.tick == 1 + K * 5          # the reset, K eager steps, three replays of K, K eager steps (the capture itself consumes none)
+    b.graph_destroy(g); b.close()
