@@ -1028,7 +1028,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         } else {
             rnd = swar::rand_nibble(Q.C.isd_shift, (uint32_t)tick & 7u, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
         }
-        swar::step4<true, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, cls4, rnd, o);
+        // Frozen lanes and goal tuples exist only without auto-reset or after a state injection; a thread none of whose lanes is
+        // in either condition (nearly every thread of an auto-resetting handle) takes the step without the code for them —
+        // 31 vector instructions fewer, 12 for the test: in this kernel every instruction shows (5.6 ns).
+        const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ Q.C.Wm1x4) | swar::is_zero(S.cb ^ Q.C.Wm1x4);
+        const bool special = Q.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
+        if (special) swar::step4<true, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, cls4, rnd, o);
+        else swar::step4<false, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, cls4, rnd, o);
         uint8_t* sw = const_cast<uint8_t*>(sp);
         __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
         __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(sw + state_stride));
