@@ -73,6 +73,7 @@ struct soccer_handle {
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
     bool stamp_poll = false;                // soccer_timer_read may watch the closing stamp of the last soccer_graph_launch change ...
     unsigned long long stamp_prev = 0;      // ... from this value (what the slot held when the replay was enqueued)
+    unsigned long long swar_launch_lanes = kSwarLaunchLanes;   // lanes per step_kernel_swar launch (SOCCER_SWAR_LAUNCH_LANES: tests of the split)
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
@@ -271,6 +272,10 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     if (h->swar_ok) h->swar_c = swar::make_consts(R.H, R.W, R.goal_lo, R.goal_hi, cfg->max_steps, R.n_isd, R.isd, P.autoreset != 0u);
     h->slip = cfg->slip_prob != 0.0;
     if (const char* e2 = std::getenv("SOCCER_ROLLOUT")) h->rollout_pref = std::atoi(e2);
+    if (const char* e3 = std::getenv("SOCCER_SWAR_LAUNCH_LANES")) {
+        const unsigned long long v = std::strtoull(e3, nullptr, 10) & ~3ull;
+        if (v >= 4ull && v <= kSwarLaunchLanes) h->swar_launch_lanes = v;
+    }
     h->E = e ? static_cast<int>(e) : 4;
 
     // Observation table (uint16 index < 65535 bounds it to a few hundred KB): global for the step kernel,
@@ -403,6 +408,8 @@ extern "C" int batched_reset(soccer_handle* h, const uint8_t* mask, const double
     return SOCCER_OK;
 }
 
+template <class T> static inline T* off(T* p, unsigned long long lanes) { return p ? p + lanes : nullptr; }   // NULL stays NULL
+
 template <bool EXPLICIT_U, bool VEC, bool SHARED>
 static void launch_step3(soccer_handle* h, const KernelParams& P, const StepIO& io) {
     const int grid = grid_for(h, (P.n + 3) / 4);
@@ -416,22 +423,30 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
     const bool swar_fit = vec && shared && h->swar_ok && (!h->slip || h->slip_swar_ok) && aligned(io.last_return, 4);
     if ((policy_only || !explicit_u) && swar_fit) {
         // the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
-        const unsigned long long blocks = ((P.n >> 2) + kBlock - 1) / kBlock;
-        const dim3 gh(static_cast<unsigned>(blocks)), b(kBlock);
         // which outputs the launch needs decides the instantiation: 0 the four result streams, 1 + the gym floats /
         // finished / last_return, 2 + final_obs / prob_code / episode histogram
         const int out = (io.prob_code || io.final_obs || P.step_stats) ? 2
                       : (io.reward_a_f32 || io.reward_b_f32 || io.finished || io.last_return) ? 1 : 0;
-        SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset, P.first, P.tick_out, P.misuse, P.step_stats ? P.hist : nullptr, P.hist_mask,
-                     h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.policy_a, P.policy_b,
-                     io.obs, io.reward, io.terminated, io.truncated, io.prob_code, io.final_obs,
-                     io.reward_a_f32, io.reward_b_f32, io.finished, io.last_return};
-#define SWAR_ARGS P.state, P.state_stride, io.act_a, io.act_b, (h->capturing ? P.tick_in : nullptr), P.n, (unsigned long long)(h->tick - 1), Q
+        const dim3 b(kBlock);
+#define SWAR_ARGS P.state + c0, P.state_stride, off(io.act_a, c0), off(io.act_b, c0), (h->capturing ? P.tick_in : nullptr), cn, (unsigned long long)(h->tick - 1), Q
 #define SWAR_GO(OV, SV, PV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 1>), gh, b, 0, h->stream, SWAR_ARGS); \
                                  else hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 0>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
 #define SWAR_SLIP(OV, PV) do { if (!h->slip) SWAR_GO(OV, false, PV); else SWAR_GO(OV, true, PV); } while (0)
 #define SWAR_OUT(PV) do { if (out == 2) SWAR_SLIP(2, PV); else if (out == 1) SWAR_SLIP(1, PV); else SWAR_SLIP(0, PV); } while (0)
-        if (policy_only) SWAR_OUT(true); else SWAR_OUT(false);
+        // The kernel's byte offsets are 32-bit (soccer_kernels.hpp): a handle beyond kSwarLaunchLanes lanes is stepped by
+        // several launches on the same tick, each handed its part of every stream; only the last one publishes the tick.
+        for (unsigned long long c0 = P.first; c0 < P.first + P.n; c0 += h->swar_launch_lanes) {
+            const unsigned long long cn = std::min<unsigned long long>(h->swar_launch_lanes, P.first + P.n - c0);
+            const bool last = c0 + cn == P.first + P.n;
+            const dim3 gh(static_cast<unsigned>(((cn >> 2) + kBlock - 1) / kBlock));
+            SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset + c0, 0ull, last ? P.tick_out : nullptr, P.misuse,
+                         P.step_stats ? P.hist : nullptr, P.hist_mask,
+                         h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.policy_a, P.policy_b,
+                         off(io.obs, c0), off(io.reward, c0), off(io.terminated, c0), off(io.truncated, c0), off(io.prob_code, c0),
+                         off(io.final_obs, c0), off(io.reward_a_f32, c0), off(io.reward_b_f32, c0), off(io.finished, c0),
+                         off(io.last_return, c0)};
+            if (policy_only) SWAR_OUT(true); else SWAR_OUT(false);
+        }
 #undef SWAR_OUT
 #undef SWAR_SLIP
 #undef SWAR_GO

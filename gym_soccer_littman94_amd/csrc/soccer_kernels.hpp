@@ -976,6 +976,7 @@ struct SwarParams {
 // Without SLIP the thread's block is the one of tick >> 3 and the lanes' draws are this tick's nibbles (swar::rand_nibble).
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the observation of
 // the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
+constexpr unsigned long long kSwarLaunchLanes = 1ull << 30;   // 4 bytes per lane (the float rewards) * 2^30 lanes: offsets below 2^32
 template <int OUT, bool SLIP = false, bool POLICY = false, int GEO = 0>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
@@ -991,18 +992,22 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
     if (FULL) { hist.fin = 0u; hist.pos = 0u; hist.neg = 0u; hist.old01 = make_ulonglong2(0ull, 0ull); hist.old2 = 0ull; }
     if (stats) hist.init_at(Q.hist, Q.hist_mask);
     if (active) {
-        const unsigned long long i0 = Q.first + (g << 2);
-        const uint8_t* sp = state_in + i0;
+        // Byte offsets are 32-bit (the host launches at most kSwarLaunchLanes lanes at a time): a uniform base plus a 32-bit
+        // per-thread offset is what the compiler turns into SGPR-base addressing (global_load v, v_off, s[base:base+1]) — no
+        // 64-bit vector add per stream (20 vector instructions of about 245 with 64-bit offsets).
+        const uint32_t i0 = (uint32_t)Q.first + ((uint32_t)g << 2);
+#define AT(base, off) (reinterpret_cast<const uint8_t*>(base) + (off))
+        const uint8_t* sp = state_in;
         swar::Group S;
-        S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp));
-        S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + state_stride));
-        S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 2 * state_stride));
-        S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 3 * state_stride));
-        S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 4 * state_stride));
-        S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sp + 5 * state_stride));
+        S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp, i0)));
+        S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + state_stride, i0)));
+        S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 2 * state_stride, i0)));
+        S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 3 * state_stride, i0)));
+        S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 4 * state_stride, i0)));
+        S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 5 * state_stride, i0)));
         uint32_t aa = 0u, ab = 0u;
-        if (!POLICY || !Q.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_a + i0));
-        if (!POLICY || !Q.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(act_b + i0));
+        if (!POLICY || !Q.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_a, i0)));
+        if (!POLICY || !Q.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_b, i0)));
         // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
         const unsigned long long tick = tick_in ? *tick_in : tick_val;
         if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
@@ -1036,38 +1041,43 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         if (special) swar::step4<true, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, cls4, rnd, o);
         else swar::step4<false, FULL, SLIP, GEO>(Q.C, S, aa, ab, sa, sb, cls4, rnd, o);
         uint8_t* sw = const_cast<uint8_t*>(sp);
-        __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(sw));
-        __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(sw + state_stride));
-        __builtin_nontemporal_store(S.rb, reinterpret_cast<uint32_t*>(sw + 2 * state_stride));
-        __builtin_nontemporal_store(S.cb, reinterpret_cast<uint32_t*>(sw + 3 * state_stride));
-        __builtin_nontemporal_store(S.ps, reinterpret_cast<uint32_t*>(sw + 4 * state_stride));
-        __builtin_nontemporal_store(S.tt, reinterpret_cast<uint32_t*>(sw + 5 * state_stride));
+        // the stores' offset is opaque to the optimiser: it would otherwise hoist the 64-bit addresses of the loads above the
+        // branch and reuse them (instruction selection works a block at a time and then no longer sees base + offset)
+        uint32_t j0 = i0; asm volatile("" : "+v"(j0));
+        const uint32_t j0x2 = j0 << 1, j0x4 = j0 << 2;
+#define ATW(base, off) (reinterpret_cast<uint8_t*>(base) + (off))
+        __builtin_nontemporal_store(S.ra, reinterpret_cast<uint32_t*>(ATW(sw, j0)));
+        __builtin_nontemporal_store(S.ca, reinterpret_cast<uint32_t*>(ATW(sw + state_stride, j0)));
+        __builtin_nontemporal_store(S.rb, reinterpret_cast<uint32_t*>(ATW(sw + 2 * state_stride, j0)));
+        __builtin_nontemporal_store(S.cb, reinterpret_cast<uint32_t*>(ATW(sw + 3 * state_stride, j0)));
+        __builtin_nontemporal_store(S.ps, reinterpret_cast<uint32_t*>(ATW(sw + 4 * state_stride, j0)));
+        __builtin_nontemporal_store(S.tt, reinterpret_cast<uint32_t*>(ATW(sw + 5 * state_stride, j0)));
         if (Q.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
-                                               reinterpret_cast<unsigned long long*>(Q.obs + i0));
-        if (Q.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(Q.reward + i0));
-        if (Q.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(Q.terminated + i0));
-        if (Q.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(Q.truncated + i0));
+                                               reinterpret_cast<unsigned long long*>(ATW(Q.obs, j0x2)));
+        if (Q.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(ATW(Q.reward, j0)));
+        if (Q.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(ATW(Q.terminated, j0)));
+        if (Q.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(ATW(Q.truncated, j0)));
         if (OUT >= 1) {
             if (Q.reward_a_f32 || Q.reward_b_f32) {                 // the rewards as the floats a gym caller reads (:400-402)
                 const int32_t r = (int32_t)o.rew;
                 const float f0 = (float)((r << 24) >> 24), f1 = (float)((r << 16) >> 24), f2 = (float)((r << 8) >> 24), f3 = (float)(r >> 24);
                 typedef float f4 __attribute__((ext_vector_type(4)));
-                if (Q.reward_a_f32) { const f4 va = {f0, f1, f2, f3}; __builtin_nontemporal_store(va, reinterpret_cast<f4*>(Q.reward_a_f32 + i0)); }
+                if (Q.reward_a_f32) { const f4 va = {f0, f1, f2, f3}; __builtin_nontemporal_store(va, reinterpret_cast<f4*>(ATW(Q.reward_a_f32, j0x4))); }
                 if (Q.reward_b_f32) { const f4 vb = {0.0f - f0, 0.0f - f1, 0.0f - f2, 0.0f - f3};
-                                      __builtin_nontemporal_store(vb, reinterpret_cast<f4*>(Q.reward_b_f32 + i0)); }
+                                      __builtin_nontemporal_store(vb, reinterpret_cast<f4*>(ATW(Q.reward_b_f32, j0x4))); }
             }
-            if (Q.finished) __builtin_nontemporal_store(o.term | o.trunc, reinterpret_cast<uint32_t*>(Q.finished + i0));
+            if (Q.finished) __builtin_nontemporal_store(o.term | o.trunc, reinterpret_cast<uint32_t*>(ATW(Q.finished, j0)));
             // A's return of the episode that just ended = the reward of its last step (only that step can carry one);
             // lanes whose episode goes on keep what the stream holds.  Rare: one read-modify-write of the thread's own dword.
             if (Q.last_return && (o.finished & swar::K80)) {
-                uint32_t* lr = reinterpret_cast<uint32_t*>(Q.last_return + i0);
+                uint32_t* lr = reinterpret_cast<uint32_t*>(ATW(Q.last_return, j0));
                 *lr = swar::bfi(swar::mask_of(o.finished), o.rew, *lr);
             }
         }
         if (FULL) {
-            if (Q.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(Q.prob_code + i0));
+            if (Q.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(ATW(Q.prob_code, j0)));
             if (Q.final_obs) __builtin_nontemporal_store((unsigned long long)o.fin_lo | ((unsigned long long)o.fin_hi << 32),
-                                                         reinterpret_cast<unsigned long long*>(Q.final_obs + i0));
+                                                         reinterpret_cast<unsigned long long*>(ATW(Q.final_obs, j0x2)));
             // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends the episode
             if (stats) hist.add_totals((uint32_t)__builtin_popcount(o.finished & swar::K80),
                                        (int32_t)__builtin_popcount(o.rew & swar::K01) - 2 * (int32_t)__builtin_popcount(o.rew & swar::K80),
@@ -1075,6 +1085,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         }
         if (o.frozen) Q.misuse[0] = 1u;
         if (o.bad_action) Q.misuse[1] = 1u;
+#undef AT
+#undef ATW
     }
     if (stats) hist.flush_at(Q.hist, Q.hist_mask);
 }

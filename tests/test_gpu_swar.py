@@ -596,3 +596,55 @@ def test_clock_stamps_and_the_captured_timer():
         b.stamp(256)
     assert b.tick == 1 + K * 5          # the reset, K eager steps, three replays of K, K eager steps (the capture itself consumes none)
     b.graph_destroy(g); b.close()
+
+
+@pytest.mark.parametrize("slip", [0.0, 0.2])
+def test_a_step_split_into_several_launches_is_the_same_step(slip, monkeypatch):
+    """step_kernel_swar addresses every stream with 32-bit byte offsets, so a handle beyond 2^30 lanes is stepped by several
+    launches on one tick, each handed its part of every stream (launch_step in soccer_hip.hip).  SOCCER_SWAR_LAUNCH_LANES
+    (read by soccer_create) shrinks the part so that the split can be tested at a size the oracle finishes: 3 parts + a
+    short one + a ragged 3-lane tail, every output stream, the histogram and last_return, eagerly and as a captured graph."""
+    monkeypatch.setenv("SOCCER_SWAR_LAUNCH_LANES", "4096")
+    n, T = 3 * 4096 + 1028 + 3, 6
+    rng = np.random.default_rng(12)
+    b = SoccerBatch(n, 5, 4, slip, seed=23, autoreset=True, lane_offset=4 * 77, step_stats=True)
+    monkeypatch.delenv("SOCCER_SWAR_LAUNCH_LANES")
+    o = Oracle(5, 4, slip, n=n, seed=23, autoreset=True, lane_offset=4 * 77)
+    io = _IO(b, True)
+    last = b.alloc(n, np.int8).fill(0x55); want = np.full(n, 0x55, np.int8)
+    b.reset(); o.reset()
+    for k in range(60):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        io.aa.upload(a[0]); io.ab.upload(a[1])
+        b.step(io.aa, io.ab, obs=io.obs, reward=io.rew, terminated=io.term, truncated=io.trunc, prob_code=io.code, final_obs=io.fin,
+               reward_a_f32=io.rfa, reward_b_f32=io.rfb, finished=io.done, last_return=last)
+        c = o.step(a[0], a[1])
+        got = dict(obs=io.obs.download(), reward=io.rew.download(), terminated=io.term.download(), truncated=io.trunc.download(),
+                   prob_code=io.code.download(), final_obs=io.fin.download())
+        _check(got, c, k)
+        _check_gym_outputs(got, io.rfa.download(), io.rfb.download(), io.done.download())
+        want = np.where((c["terminated"] | c["truncated"]) != 0, c["reward"], want)
+        np.testing.assert_array_equal(last.download(), want)
+    # captured: T steps per replay, each of them split the same way; the tick slot is published once per step
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    A2 = b.alloc((T, n + 5), np.int8); B2 = b.alloc((T, n + 5), np.int8)   # rows n + 5 apart: every row 8-byte aligned
+    obs = b.alloc((T, n + 5), np.uint16); rew = b.alloc((T, n + 5), np.int8)
+    term = b.alloc((T, n + 5), np.uint8); trunc = b.alloc((T, n + 5), np.uint8)
+    pad = np.zeros((T, 5), np.int8)
+    A2.upload(np.concatenate([acts[:, 0], pad], axis=1)); B2.upload(np.concatenate([acts[:, 1], pad], axis=1))
+    b.graph_begin()
+    for k in range(T):
+        b.step_plain(A2.row(k), B2.row(k), obs.row(k), rew.row(k), term.row(k), trunc.row(k))
+    g = b.graph_end()
+    for rep in range(2):
+        b.graph_launch(g, 1)
+        O, R, TE, TR = obs.download(), rew.download(), term.download(), trunc.download()
+        for k in range(T):
+            c = o.step(acts[k, 0], acts[k, 1])
+            np.testing.assert_array_equal(O[k, :n], c["obs"]); np.testing.assert_array_equal(R[k, :n], c["reward"])
+            np.testing.assert_array_equal(TE[k, :n], c["terminated"]); np.testing.assert_array_equal(TR[k, :n], c["truncated"])
+    b.graph_destroy(g)
+    _state_equal(b, o)
+    hist, misuse = b.stats()
+    assert misuse == 0 and b.tick == o.tick
+    b.close()
