@@ -69,6 +69,7 @@ struct soccer_handle {
     swar::Consts swar_c{}; bool swar_ok = false;
     swar::SlipConsts slip_c{}; bool slip_swar_ok = false;   // integer slip selection usable by the byte-parallel kernels
     uint32_t* d_slip_lut = nullptr;         // SlipTables::lut + T for the table form of the selection (when lut_ok)
+    uint32_t* d_slip_step_lut = nullptr;    // SlipTables::lut_step + T: the single step's table (when lut_step_ok)
     size_t hist_slots = kHistSlots;         // per-wave histogram slots (a power of two; see soccer_create)
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
     bool stamp_poll = false;                // soccer_timer_read may watch the closing stamp of the last soccer_graph_launch change ...
@@ -125,7 +126,7 @@ static void free_handle(soccer_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_slip_lut};
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_slip_lut, h->d_slip_step_lut};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -262,6 +263,13 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
             std::memcpy(img.data() + kSlipBuckets / 4, ST.T, sizeof(ST.T));
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_slip_lut), img.size() * sizeof(uint32_t)));
             CREATE_TRY(hipMemcpy(h->d_slip_lut, img.data(), img.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        if (ST.lut_step_ok && !std::getenv("SOCCER_STEP_SLIP_ONE_BY_ONE")) {      // (the variable: tests and A/B runs of the other form)
+            std::vector<uint32_t> img(kSlipStepLdsWords, 0xFFFFFFFFu);
+            std::memcpy(img.data(), ST.lut_step, kSlipStepBuckets);
+            std::memcpy(img.data() + kSlipStepBuckets / 4, ST.T, sizeof(ST.T));
+            CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_slip_step_lut), img.size() * sizeof(uint32_t)));
+            CREATE_TRY(hipMemcpy(h->d_slip_step_lut, img.data(), img.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
         h->slip_c = swar::SlipConsts{};
         for (int i = 0; i < 9; ++i) h->slip_c.CB[i] = ST.CB[i];
@@ -431,7 +439,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
 #define SWAR_ARGS P.state + c0, P.state_stride, off(io.act_a, c0), off(io.act_b, c0), (h->capturing ? P.tick_in : nullptr), cn, (unsigned long long)(h->tick - 1), Q
 #define SWAR_GO(OV, SV, PV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 1>), gh, b, 0, h->stream, SWAR_ARGS); \
                                  else hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 0>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
-#define SWAR_SLIP(OV, PV) do { if (!h->slip) SWAR_GO(OV, false, PV); else SWAR_GO(OV, true, PV); } while (0)
+#define SWAR_SLIP(OV, PV) do { if (!h->slip) SWAR_GO(OV, 0, PV); else if (h->d_slip_step_lut) SWAR_GO(OV, 2, PV); else SWAR_GO(OV, 1, PV); } while (0)
 #define SWAR_OUT(PV) do { if (out == 2) SWAR_SLIP(2, PV); else if (out == 1) SWAR_SLIP(1, PV); else SWAR_SLIP(0, PV); } while (0)
         // The kernel's byte offsets are 32-bit (soccer_kernels.hpp): a handle beyond kSwarLaunchLanes lanes is stepped by
         // several launches on the same tick, each handed its part of every stream; only the last one publishes the tick.
@@ -441,7 +449,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
             const dim3 gh(static_cast<unsigned>(((cn >> 2) + kBlock - 1) / kBlock));
             SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset + c0, 0ull, last ? P.tick_out : nullptr, P.misuse,
                          P.step_stats ? P.hist : nullptr, P.hist_mask,
-                         h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), P.policy_a, P.policy_b,
+                         h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_slip_step_lut, P.policy_a, P.policy_b,
                          off(io.obs, c0), off(io.reward, c0), off(io.terminated, c0), off(io.truncated, c0), off(io.prob_code, c0),
                          off(io.final_obs, c0), off(io.reward_a_f32, c0), off(io.reward_b_f32, c0), off(io.finished, c0),
                          off(io.last_return, c0)};

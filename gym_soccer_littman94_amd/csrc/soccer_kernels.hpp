@@ -951,7 +951,8 @@ struct SwarParams {
     unsigned long long* tick_out;
     unsigned int* misuse;                   // [0] a frozen lane was stepped (:376), [1] an action byte outside 0..4 (:393)
     unsigned long long* hist; uint32_t hist_mask;   // OUT == 2: episode histogram slots (SOCCER_F_STEP_STATS), or nullptr
-    swar::SlipConsts L; const swar::Quad* sub;   // SLIP: integer cumulative weights / the nine rows of quarter thresholds
+    swar::SlipConsts L; const swar::Quad* sub;   // SLIPM == 1: integer cumulative weights / the nine rows of quarter thresholds
+    const uint32_t* slip_lut;               // SLIPM == 2: SlipTables::lut_step (kSlipStepBuckets bytes), then T (kSlipThresholds words)
     const int8_t* policy_a; const int8_t* policy_b;   // POLICY: the fixed side's int8[nS] policy (the other is nullptr)
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs;                          // OUT == 2
@@ -967,53 +968,84 @@ struct SwarParams {
 // accesses measured best; 8 or 16 lanes per thread (dwordx2 / dwordx4), plain or write-through stores and 512-thread
 // workgroups were all equal or slower, and an instantiation without the frozen-lane / goal-tuple code was not faster
 // (the kernel is bound by launch + memory latency, not by vector issue any more).
-// SLIP: handles with slip_prob > 0 whose integer slip decision is the reference's for every draw (SlipTables::swar_ok):
-// each lane counts the integer cumulative weights and its combination's quarter points below its draw (the threshold rows
-// are gathered while the state loads are still in flight: they depend on the random word only), the rest stays byte-parallel.
-// (The rollout's bucket-table selection does not pay here: gathered from global memory, the 16 KB byte table + threshold list
-// is two dependent L2 round trips — 5.15 us per launch, the same as comparing one by one — and a 64 KB table with the
-// candidate inlined, one gather, thrashes the 16 KB L1: 6.05 us.)
+// SLIPM: handles with slip_prob > 0 whose integer slip decision is the reference's for every draw (SlipTables::swar_ok).
+//   1  each lane counts the integer cumulative weights and its combination's quarter points below its draw, one by one (the
+//      threshold rows are gathered while the state loads are still in flight: they depend on the random word only) — ~30 vector
+//      instructions per lane;
+//   2  (SlipTables::lut_step_ok: slips within about [0.09, 0.96]) by table, like the rollout: a launch lives for one step, so
+//      each WAVE stages what one 16-byte load per lane brings in — 1 024 byte buckets over the draw's top 10 bits — and the
+//      threshold list (one entry per lane), issued ahead of the state loads and parked in the wave's own 1 280 bytes of LDS while those
+//      are in flight (no workgroup barrier); a lane then needs two LDS reads and two exact compares (~9 instructions).  The table cannot be gathered from global memory instead: a wave's
+//      loads return in order, so a gather issued after the state loads waits for all of them, and the 16 KB table of the
+//      rollout is two dependent L2 round trips on top (5.15 us per launch, the same as comparing one by one; a 64 KB table with
+//      the candidate inlined, one gather, thrashes the 16 KB L1: 6.05 us).
 // Without SLIP the thread's block is the one of tick >> 3 and the lanes' draws are this tick's nibbles (swar::rand_nibble).
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the observation of
 // the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
 constexpr unsigned long long kSwarLaunchLanes = 1ull << 30;   // 4 bytes per lane (the float rewards) * 2^30 lanes: offsets below 2^32
-template <int OUT, bool SLIP = false, bool POLICY = false, int GEO = 0>
+template <int OUT, int SLIPM = 0, bool POLICY = false, int GEO = 0>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
                                                            const unsigned long long* tick_in,
                                                            unsigned long long n, unsigned long long tick_val,
                                                            const SwarParams Q) {
     constexpr bool FULL = OUT == 2;
+    constexpr bool SLIP = SLIPM != 0;
+    static_assert(kSlipStepBuckets == 64 * 16 && kSlipThresholds <= 64, "one 16-byte piece of the table per lane of a wave");
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     const bool active = (g << 2) < n;                                // n is a multiple of 4 here
-    if (!FULL && !active) return;
+    // SLIPM == 2: this lane's 16 bytes of the bucket table and its entry of the threshold list — the oldest loads
+    // of the wave, so the wait for them does not wait for the state.  Every WAVE keeps a copy of its own: no workgroup barrier.
+    const uint32_t lane = threadIdx.x & 63u;
+    uint4 st_lut = make_uint4(0u, 0u, 0u, 0u); uint32_t st_thr = 0u;
+    if (SLIPM == 2) {
+        st_lut = reinterpret_cast<const uint4*>(Q.slip_lut)[lane];
+        st_thr = Q.slip_lut[kSlipStepBuckets / 4 + lane];                 // (the list is padded to 64 entries)
+    }
+    if (SLIPM != 2 && !FULL && !active) return;
     HistAcc<true> hist;
     const bool stats = FULL && Q.hist != nullptr;                    // wave-uniform
     if (FULL) { hist.fin = 0u; hist.pos = 0u; hist.neg = 0u; hist.old01 = make_ulonglong2(0ull, 0ull); hist.old2 = 0ull; }
     if (stats) hist.init_at(Q.hist, Q.hist_mask);
-    if (active) {
-        // Byte offsets are 32-bit (the host launches at most kSwarLaunchLanes lanes at a time): a uniform base plus a 32-bit
-        // per-thread offset is what the compiler turns into SGPR-base addressing (global_load v, v_off, s[base:base+1]) — no
-        // 64-bit vector add per stream (20 vector instructions of about 245 with 64-bit offsets).
-        const uint32_t i0 = (uint32_t)Q.first + ((uint32_t)g << 2);
+    // Byte offsets are 32-bit (the host launches at most kSwarLaunchLanes lanes at a time): a uniform base plus a 32-bit
+    // per-thread offset is what the compiler turns into SGPR-base addressing (global_load v, v_off, s[base:base+1]) — no
+    // 64-bit vector add per stream (20 vector instructions of about 245 with 64-bit offsets).
+    const uint32_t i0 = (uint32_t)Q.first + ((uint32_t)g << 2);
 #define AT(base, off) (reinterpret_cast<const uint8_t*>(base) + (off))
-        const uint8_t* sp = state_in;
-        swar::Group S;
-        S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp, i0)));
-        S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + state_stride, i0)));
-        S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 2 * state_stride, i0)));
-        S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 3 * state_stride, i0)));
-        S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 4 * state_stride, i0)));
-        S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 5 * state_stride, i0)));
-        uint32_t aa = 0u, ab = 0u;
-        if (!POLICY || !Q.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_a, i0)));
-        if (!POLICY || !Q.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_b, i0)));
-        // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
-        const unsigned long long tick = tick_in ? *tick_in : tick_val;
-        if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
-        const unsigned long long q = (Q.lane_offset + i0) >> 2;     // the thread's 4 lanes are exactly one Philox block
-        const unsigned long long bt = block_tick<SLIP>(tick);
-        const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), Q.key0, Q.key1);
+    const uint8_t* sp = state_in;
+    swar::Group S{0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t aa = 0u, ab = 0u;
+    // SLIPM == 2: the state loads are issued by every lane (lanes beyond n re-read the first group) — under a branch the wait for
+    // the table loads ahead of them could no longer count on their order and would become a wait for everything
+    const bool fetch = SLIPM == 2 ? true : active;
+    const uint32_t l0 = SLIPM == 2 ? (active ? i0 : (uint32_t)Q.first) : i0;
+    if (fetch) {
+        S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp, l0)));
+        S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + state_stride, l0)));
+        S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 2 * state_stride, l0)));
+        S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 3 * state_stride, l0)));
+        S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 4 * state_stride, l0)));
+        S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 5 * state_stride, l0)));
+        if (!POLICY || !Q.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_a, l0)));
+        if (!POLICY || !Q.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_b, l0)));
+    }
+    // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
+    const unsigned long long tick = tick_in ? *tick_in : tick_val;
+    const unsigned long long q = (Q.lane_offset + i0) >> 2;     // the thread's 4 lanes are exactly one Philox block
+    const unsigned long long bt = block_tick<SLIP>(tick);
+    const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), Q.key0, Q.key1);
+    const uint8_t* slip_lut = nullptr; const uint32_t* slip_thr = nullptr;
+    if (SLIPM == 2) {                                                // park the table: all 64 lanes, whether their lanes exist or not
+        __shared__ __attribute__((aligned(16))) uint32_t s_slip[SLIPM == 2 ? kBlock / 64 : 1][SLIPM == 2 ? kSlipStepLdsWords : 4];
+        uint32_t* mine = s_slip[threadIdx.x >> 6];
+        reinterpret_cast<uint4*>(mine)[lane] = st_lut;
+        mine[kSlipStepBuckets / 4 + lane] = st_thr;
+        // a wave's LDS operations complete in order; the fences keep the compiler from moving the reads below above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        slip_lut = reinterpret_cast<const uint8_t*>(mine); slip_thr = mine + kSlipStepBuckets / 4;
+        if (!FULL && !active) return;
+    }
+    if (active) {
         if (POLICY) {                                               // the fixed side acts on the current observation (:187-188)
             uint32_t s_lo, s_hi;
             const uint32_t cc0 = swar::bfi(swar::mask_of(S.ps << 7), S.cb, S.ca);
@@ -1028,7 +1060,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         swar::Rand4 rnd;
         if (SLIP) {
             uint32_t k4 = 0u;
-            swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
+            if (SLIPM == 2) {
+                const uint32_t p4 = swar::slip_count4_lut<kSlipStepBucketBits, kSlipStepCompares>(slip_lut, slip_thr, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
+                // the counts need the random words and the table only: the empty statement ties the loaded actions to them, so that
+                // the wait for the state loads comes after the table reads and not before
+                asm volatile("" : "+v"(aa), "+v"(ab) : "v"(p4));
+                swar::slip_from_count4(p4, Q.L.c_off, swar::canon4(aa), swar::canon4(ab), sa, sb, k4, cls4);
+            }
+            else swar::slip_select4(Q.L, Q.sub, swar::canon4(aa), swar::canon4(ab), blk.w[0], blk.w[1], blk.w[2], blk.w[3], sa, sb, k4, cls4);
             rnd = swar::Rand4{k4 << 6, swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> Q.C.isd_shift};
         } else {
             rnd = swar::rand_nibble(Q.C.isd_shift, (uint32_t)tick & 7u, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
@@ -1085,6 +1124,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         }
         if (o.frozen) Q.misuse[0] = 1u;
         if (o.bad_action) Q.misuse[1] = 1u;
+        // (published last: a store in flight ahead of the loads' waits would turn them into waits for everything — loads and
+        // stores share the wave's counter and complete out of order with respect to each other)
+        if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
 #undef AT
 #undef ATW
     }
@@ -1426,8 +1468,8 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int st = sb + k; st = st < 0 ? 0 : st; st = st < IO.n_steps ? st : IO.n_steps - 1;
-            if (load_a) nx[2 * k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + i0));
-            if (load_b) nx[2 * k + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + i0));
+            if (load_a) nx[2 * k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + (uint32_t)i0));
+            if (load_b) nx[2 * k + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + (uint32_t)i0));
         }
     };
     if (STAGED) fetch(-(int)((uint32_t)tick0 & 7u));

@@ -27,7 +27,7 @@
 
 namespace soccer {
 
-constexpr int kSlipBucketBits = 14, kSlipBuckets = 1 << kSlipBucketBits, kSlipThresholds = 40;
+constexpr int kSlipBucketBits = 14, kSlipBuckets = 1 << kSlipBucketBits;   // (kSlipThresholds = 40 and the single step's table: soccer_swar.hpp)
 constexpr int kSlipLdsWords = kSlipBuckets / 4 + kSlipThresholds;       // what a kernel stages: the table, then the thresholds
 
 struct SlipTables {
@@ -53,6 +53,9 @@ struct SlipTables {
     uint8_t lut[kSlipBuckets];
     bool lut_ok;                 // swar_ok, T ascending, and no bucket holds two thresholds (needs s^2 / 16 and (1 - s)^2 / 4 >= 2^-14:
                                  // slips within about [0.032, 0.984]; the others compare threshold by threshold)
+    uint8_t lut_step[kSlipStepBuckets];   // the same over 2^20-wide buckets (step_kernel_swar<.., 2, ..>)
+    bool lut_step_ok;            // swar_ok, T ascending, at most kSlipStepCompares thresholds inside any bucket (slips within about
+                                 // [0.09, 0.96])
 };
 
 inline SlipTables build_slip_tables(double slip_prob) {
@@ -126,14 +129,22 @@ inline SlipTables build_slip_tables(double slip_prob) {
     for (uint32_t i = 0; i < T.nb && i < 9; ++i) { T.T[4 * i] = T.sub[i].y; T.T[4 * i + 1] = T.sub[i].z; T.T[4 * i + 2] = T.sub[i].w; T.T[4 * i + 3] = T.CB[i]; }
     bool lut_ok = T.swar_ok;
     for (uint32_t j = 1; j < 4 * T.nb; ++j) lut_ok = lut_ok && T.T[j - 1] <= T.T[j];
-    constexpr int shift = 30 - kSlipBucketBits;
-    for (int b = 0; b < kSlipBuckets; ++b) {
-        const uint32_t lo = (uint32_t)b << shift, hi = lo + (1u << shift);
-        uint32_t below = 0, inside = 0;
-        for (uint32_t j = 0; j < 4 * T.nb; ++j) { if (T.T[j] <= lo) ++below; else if (T.T[j] < hi) ++inside; }
-        T.lut[b] = (uint8_t)below;
-        if (inside > 1u) lut_ok = false;
-    }
+    // lut[b] = how many thresholds lie at or below the first draw of bucket b; returns the largest number strictly inside one bucket
+    auto fill = [&](int bits, uint8_t* lut) -> uint32_t {
+        const int shift = 30 - bits;
+        uint32_t worst = 0;
+        for (int b = 0; b < (1 << bits); ++b) {
+            const uint32_t lo = (uint32_t)b << shift, hi = lo + (1u << shift);
+            uint32_t below = 0, inside = 0;
+            for (uint32_t j = 0; j < 4 * T.nb; ++j) { if (T.T[j] <= lo) ++below; else if (T.T[j] < hi) ++inside; }
+            lut[b] = (uint8_t)below;
+            worst = std::max(worst, inside);
+        }
+        return worst;
+    };
+    const bool ascending = lut_ok;
+    if (fill(kSlipBucketBits, T.lut) > 1u) lut_ok = false;
+    T.lut_step_ok = ascending && fill(kSlipStepBucketBits, T.lut_step) <= (uint32_t)kSlipStepCompares;
     T.lut_ok = lut_ok;
     return T;
 }

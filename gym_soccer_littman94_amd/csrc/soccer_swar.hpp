@@ -33,6 +33,15 @@
 #endif
 
 namespace soccer {
+// Slip selection by table (SlipTables in soccer_slip.hpp, swar::slip_select4_lut below): the ascending threshold list has
+// kSlipThresholds entries (4 per combination, padded).
+constexpr int kSlipThresholds = 40;
+// The single step's table: a launch lives for one step, so its waves can stage only what one load per lane brings in — 64 lanes x
+// 16 bytes = 1 024 byte buckets over the draw's top 10 bits; up to kSlipStepCompares thresholds may lie inside a bucket and are
+// compared exactly.
+constexpr int kSlipStepBucketBits = 10, kSlipStepBuckets = 1 << kSlipStepBucketBits, kSlipStepCompares = 2;
+constexpr int kSlipStepLdsWords = kSlipStepBuckets / 4 + 64;     // the table, then the threshold list padded to one entry per lane
+
 namespace swar {
 
 // ---- the four machine operations the byte-parallel code leans on ----------------------------------------------
@@ -338,25 +347,38 @@ SOCCER_HD void slip_select4(const SlipConsts& L, const Quad* sub, uint32_t aa, u
     slip_moves4(c4, aa, ab, sa, sb, cls4);
 }
 
-// The same selection by table (SlipTables::lut / T, staged in LDS): the draw's top 14 bits give the number of thresholds that
-// are surely at or below it, the one threshold that can lie inside the bucket is compared exactly, and the count
-// p = 4 * position + quarter splits into both answers for all four lanes at once.  ~7 instead of ~30 vector instructions per lane.
-SOCCER_HD void slip_select4_lut(const uint8_t* lut, const uint32_t* T, uint32_t c_off, uint32_t aa, uint32_t ab,
-                                uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
-                                uint32_t& sa, uint32_t& sb, uint32_t& k4, uint32_t& cls4) {
+// The same selection by table (SlipTables::lut / T, staged in LDS): the draw's top BITS bits give the number of thresholds that
+// are surely at or below it, the at most NCMP thresholds that can lie inside the bucket are compared exactly, and the count
+// p = 4 * position + quarter splits into both answers for all four lanes at once.  ~7 instead of ~30 vector instructions per lane
+// (rollouts: 14 bits, one compare — SlipTables::lut; single steps: 10 bits, two compares — SlipTables::lut_step).
+template <int BITS = 14, int NCMP = 1>
+SOCCER_HD uint32_t slip_count4_lut(const uint8_t* lut, const uint32_t* T, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
     const uint32_t w[4] = {w0, w1, w2, w3};
-    uint32_t p4 = 0u;
+    uint32_t p4 = 0u;                                                      // per lane: the number of thresholds <= its draw
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int j = 0; j < 4; ++j) {
         const uint32_t m = w[j] >> 2;
-        const uint32_t below = lut[w[j] >> 18];                            // bucket = m >> 16
-        const uint32_t p = below + (m >= T[below] ? 1u : 0u);
+        const uint32_t below = lut[w[j] >> (32 - BITS)];                   // bucket = m >> (30 - BITS)
+        uint32_t p = below;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int c = 0; c < NCMP; ++c) p += m >= T[below + c] ? 1u : 0u;
         p4 |= p << (8 * j);
     }
+    return p4;
+}
+SOCCER_HD void slip_from_count4(uint32_t p4, uint32_t c_off, uint32_t aa, uint32_t ab, uint32_t& sa, uint32_t& sb, uint32_t& k4, uint32_t& cls4) {
     k4 = p4 & 0x03030303u;
     slip_moves4(((p4 >> 2) & 0x3f3f3f3fu) + c_off * K01, aa, ab, sa, sb, cls4);
+}
+template <int BITS = 14, int NCMP = 1>
+SOCCER_HD void slip_select4_lut(const uint8_t* lut, const uint32_t* T, uint32_t c_off, uint32_t aa, uint32_t ab,
+                                uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                                uint32_t& sa, uint32_t& sb, uint32_t& k4, uint32_t& cls4) {
+    slip_from_count4(slip_count4_lut<BITS, NCMP>(lut, T, w0, w1, w2, w3), c_off, aa, ab, sa, sb, k4, cls4);
 }
 
 // Observation index of four tuples (ra, ca, rb, cb, p): 1 + 2 * (iA * (NI - 1) + iB - (iB > iA)) + p over interior-cell

@@ -23,7 +23,8 @@ static void st4(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
 // swar_draws_host below checks the eight-ticks-per-block extraction of slip_prob == 0 handles.
 static int geo = -1;     // -1: as the library (tables on small pitches); 0: force the arithmetic geometry
 extern "C" void swar_set_geo(int g) { geo = g; }
-static int sel_mode = 1; // slip selection: 1 threshold by threshold (slip_select4), 2 by table (slip_select4_lut; -4 if the slip has none)
+static int sel_mode = 1; // slip selection: 1 threshold by threshold (slip_select4), 2 by the rollout's table (slip_select4_lut: 14 bits,
+                         // one compare), 3 by the single step's (10 bits, two compares); -4 if the slip has no such table
 extern "C" void swar_set_slip_select(int m) { sel_mode = m; }
 
 extern "C" int swar_step_host(int width, int height, int max_steps, int autoreset, int general, int full, long n,
@@ -41,6 +42,7 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
         ST = build_slip_tables(slip_prob);
         if (!ST.swar_ok) return -3;
         if (sel_mode == 2 && !ST.lut_ok) return -4;
+        if (sel_mode == 3 && !ST.lut_step_ok) return -4;
         for (int i = 0; i < 9; ++i) L.CB[i] = ST.CB[i];
         L.c_off = ST.c_off;
     }
@@ -51,6 +53,8 @@ extern "C" int swar_step_host(int width, int height, int max_steps, int autorese
         const uint32_t* w = words + i;
         uint32_t s_a = 0u, s_b = 0u, k4 = 0u, c4 = 0u;
         if (slip && sel_mode == 2) swar::slip_select4_lut(ST.lut, ST.T, L.c_off, swar::canon4(a), swar::canon4(b), w[0], w[1], w[2], w[3], s_a, s_b, k4, c4);
+        else if (slip && sel_mode == 3) swar::slip_select4_lut<kSlipStepBucketBits, kSlipStepCompares>(ST.lut_step, ST.T, L.c_off, swar::canon4(a), swar::canon4(b),
+                                                                                                    w[0], w[1], w[2], w[3], s_a, s_b, k4, c4);
         else if (slip) swar::slip_select4(L, ST.sub, swar::canon4(a), swar::canon4(b), w[0], w[1], w[2], w[3], s_a, s_b, k4, c4);
         swar::Rand4 rnd = swar::rand_words(C.isd_shift, w[0], w[1], w[2], w[3]);
         if (slip) rnd.kq = k4 << 6;
@@ -119,6 +123,6 @@ extern "C" void swar_draws_host(const uint32_t* w, uint8_t* out) {
 extern "C" void swar_slip_tables(double slip_prob, uint32_t* cb9, uint32_t* sub36, uint32_t* flags, double* w4) {
     const SlipTables T = build_slip_tables(slip_prob);
     for (int i = 0; i < 9; ++i) { cb9[i] = T.CB[i]; sub36[4 * i] = T.sub[i].x; sub36[4 * i + 1] = T.sub[i].y; sub36[4 * i + 2] = T.sub[i].z; sub36[4 * i + 3] = T.sub[i].w; }
-    flags[0] = T.slip_int; flags[1] = T.swar_ok ? 1u : 0u; flags[2] = T.nb; flags[3] = T.c_off; flags[4] = T.lut_ok ? 1u : 0u;
+    flags[0] = T.slip_int; flags[1] = T.swar_ok ? 1u : 0u; flags[2] = T.nb; flags[3] = T.c_off; flags[4] = T.lut_ok ? 1u : 0u; flags[5] = T.lut_step_ok ? 1u : 0u;
     for (int i = 0; i < 4; ++i) w4[i] = T.w[i];
 }

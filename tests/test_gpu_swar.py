@@ -648,3 +648,27 @@ def test_a_step_split_into_several_launches_is_the_same_step(slip, monkeypatch):
     hist, misuse = b.stats()
     assert misuse == 0 and b.tick == o.tick
     b.close()
+
+
+@pytest.mark.parametrize("slip", [0.1, 0.2, 0.9, 1.0, 2.0 / 3.0])
+def test_both_slip_selections_of_the_single_step_agree(slip, monkeypatch):
+    """step_kernel_swar<.., SLIPM, ..>: 1 compares the thresholds one by one, 2 reads the 10-bit bucket table each wave parks
+    in LDS + two exact compares (slips within about [0.09, 0.96], and 1.0).  SOCCER_STEP_SLIP_ONE_BY_ONE (read by soccer_create)
+    keeps a handle on the first form: same seed, same actions -> the same streams as the table form and as the oracle, on a lane
+    count that leaves the last wave partly filled (its idle lanes still carry their piece of the table)."""
+    n = 4096 + 4 * 37
+    rng = np.random.default_rng(int(slip * 1000))
+    monkeypatch.setenv("SOCCER_STEP_SLIP_ONE_BY_ONE", "1")
+    b1 = SoccerBatch(n, 5, 4, slip, seed=5, autoreset=True, step_stats=True)
+    monkeypatch.delenv("SOCCER_STEP_SLIP_ONE_BY_ONE")
+    b2 = SoccerBatch(n, 5, 4, slip, seed=5, autoreset=True, step_stats=True)
+    o = Oracle(5, 4, slip, n=n, seed=5, autoreset=True)
+    io1, io2 = _IO(b1, True), _IO(b2, True)
+    b1.reset(); b2.reset(); o.reset()
+    for k in range(60):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        g1, g2, c = io1.step(a[0], a[1]), io2.step(a[0], a[1]), o.step(a[0], a[1])
+        _check(g1, c, k); _check(g2, c, k)
+    _state_equal(b1, o); _state_equal(b2, o)
+    np.testing.assert_array_equal(b1.stats()[0], b2.stats()[0])
+    b1.close(); b2.close()

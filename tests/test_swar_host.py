@@ -218,12 +218,12 @@ def _slip_words(slip, n, rng):
     return ((m << 2) | rng.integers(0, 4, size=n)).astype(np.uint32)
 
 
-@pytest.fixture(params=["one_by_one", "table"])
+@pytest.fixture(params=["one_by_one", "table", "step_table"])
 def selection(request, host):
-    """both forms of the per-lane slip selection the kernels have: the thresholds compared one by one (slip_select4) and the
-    bucket table over the draw's top bits + three exact compares (slip_select4_lut, what the rollout takes whenever the
-    slip's thresholds do not crowd a bucket)"""
-    host.swar_set_slip_select(1 if request.param == "one_by_one" else 2)
+    """the forms of the per-lane slip selection the kernels have: the thresholds compared one by one (slip_select4), the
+    bucket table over the draw's top 14 bits + one exact compare (slip_select4_lut, what the rollout takes whenever the
+    slip's thresholds do not crowd a bucket) and the single step's 10-bit table + two exact compares"""
+    host.swar_set_slip_select({"one_by_one": 1, "table": 2, "step_table": 3}[request.param])
     yield request.param
     host.swar_set_slip_select(1)
 
@@ -301,6 +301,11 @@ def test_integer_slip_thresholds_are_the_float64_cumsum_for_every_list_shape(hos
     assert bool(flags[4]) == bool(inside.max() <= 1), (slip, flags[4], inside.max())
     if slip in (0.1, 0.2, 0.5, 1.0 / 3.0):
         assert flags[4] == 1
+    # the single step's table: 2^20-wide buckets, up to two thresholds inside one
+    inside = np.bincount((thr[(thr > 0) & (thr < 2 ** 30) & (thr % 2 ** 20 != 0)] >> 20), minlength=1024)
+    assert bool(flags[5]) == bool(inside.max() <= 2), (slip, flags[5], inside.max())
+    if slip in (0.1, 0.2, 0.5, 1.0 / 3.0, 0.9):
+        assert flags[5] == 1
 
 
 def test_eight_ticks_share_one_block_at_slip_zero(host):
