@@ -24,7 +24,14 @@ open('profiles/%s_bench.json' % tag, 'w').write(line + '\n')
 d = json.loads(line)
 print("bench (profiled run, kt): value %.4g launch_us %.3f frac %.4f" % (d['value'], d['roofline']['launch_us'], d['roofline']['frac']))
 import os as _os
-for extra in ('bench_unprofiled.json', 'bench_driver_shape.json'):
+slipk = glob.glob(src + '/kt_slip/runc/*_kernel_stats.csv') + glob.glob(src + '/kt_slip/*kernel_stats.csv')
+if slipk:
+    shutil.copy(slipk[0], 'profiles/%s_kernel_stats_slip0p2.csv' % tag)
+    print("-- slip 0.2 (kt_slip):")
+    for r in csv.DictReader(open(slipk[0])):
+        if 'soccer::' in r['Name']:
+            print("%-100s calls %5s avg %10.1f min %8s max %8s" % (r['Name'][:100], r['Calls'], float(r['AverageNs']), r['MinNs'], r['MaxNs']))
+for extra in ('bench_unprofiled.json', 'bench_driver_shape.json', 'bench_slip_unprofiled.json'):
     if _os.path.exists(src + '/' + extra):
         l2 = open(src + '/' + extra).read().strip().split('\n')[-1]
         open('profiles/%s_%s' % (tag, extra), 'w').write(l2 + '\n')
@@ -61,7 +68,7 @@ print("traffic per launch: %.0f B" % t['step_kernel_hbm_bytes_per_launch'])
 # SQ counters (two passes) -> profiles/<tag>_sq_counters.csv: mean per dispatch and per wave
 rows = [["kernel", "counter", "dispatches", "mean_per_dispatch", "per_wave"]]
 waves = {}
-for sq in ('sq2', 'sq1'):
+for sq in ('sq2', 'sq1', 'sq_slip'):
     files = glob.glob(src + '/%s/runc/*_counter_collection.csv' % sq) + glob.glob(src + '/%s/*counter_collection.csv' % sq)
     if not files:
         continue

@@ -4,6 +4,7 @@
 #   kt_full  the same for the default command (rollouts, self-play, VectorSoccerEnv kernels)
 #   fetch / write   FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, rocprofv3 PMC slots)
 #   sq1 / sq2       SQ instruction / wait counters
+#   kt_slip / sq_slip   kernel trace and instruction counters of the same commands at slip 0.2
 # Counters are collected with --kernel-trace only (never with the runtime / hip trace domains).
 set -e
 TAG=${1:-r02}
@@ -28,6 +29,11 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 echo "sq1 done"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$OUT/sq2" -o runc -- python3 "$B" $SQ_ARGS > "$OUT/sq2.json" 2> "$OUT/sq2.err"
 echo "sq2 done"
+# slip 0.2: the step kernel's table-selection instantiation (kernel trace, then its instruction counters) + its un-profiled line
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_slip" -o runc -- python3 "$B" --slip 0.2 --steps 1000 --warmup 50 --no-cpu-baseline --no-vector-env > "$OUT/bench_slip.json" 2> "$OUT/kt_slip.err"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d "$OUT/sq_slip" -o runc -- python3 "$B" --slip 0.2 $SQ_ARGS > "$OUT/sq_slip.json" 2> "$OUT/sq_slip.err"
+python3 "$B" --slip 0.2 --steps 1000 --warmup 50 --no-cpu-baseline --no-vector-env > "$OUT/bench_slip_unprofiled.json" 2>/dev/null
+echo "slip done"
 # un-profiled reference run of the same command as kt (a profiled run clocks lower)
 python3 "$B" --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/bench_unprofiled.json" 2>/dev/null
 python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_driver_shape.json" 2>/dev/null
