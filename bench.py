@@ -334,11 +334,29 @@ def main():
             b.graph_launch(gp, 1); barrier()          # (the slots are read after the synchronisation: no clearing needed)
         ticks, khz = b.stamps(2, KG + 1)
         d_us = np.diff(ticks.astype(np.int64)) / (khz * 1e-3)
+        b.graph_destroy(gp)
+        # what one stamp kernel adds to a delta: the same replay shape with nothing but stamps in it
+        b.graph_begin()
+        for k in range(8):
+            b.stamp(2 + k)
+        gs = b.graph_end()
+        for _ in range(3):
+            barrier()
+            b.graph_launch(gs, 1); barrier()
+        st, _ = b.stamps(2, 8)
+        stamp_us = float(np.median(np.diff(st.astype(np.int64))[2:]) / (khz * 1e-3))
+        b.graph_destroy(gs)
+        rest = float(d_us[4:].mean()) if KG > 4 else None
         launch_profile = {"what": "device-clock deltas between stamps placed after every launch of one %d-launch replay "
                                   "(each delta = one step launch + one stamp kernel)" % KG,
                           "us": [round(float(x), 3) for x in d_us],
-                          "first4_mean_us": float(d_us[:4].mean()), "rest_mean_us": float(d_us[4:].mean()) if KG > 4 else None}
-        b.graph_destroy(gp)
+                          "first4_mean_us": float(d_us[:4].mean()), "rest_mean_us": rest,
+                          "stamp_kernel_us": stamp_us,
+                          "steady_launch_us": rest - stamp_us if rest is not None else None,
+                          "steady_frac": (ALGO_BYTES_PER_ENV_STEP * N / ((rest - stamp_us) * 1e-6)) / 8e12 if rest is not None else None,
+                          "note": "steady_launch_us = rest_mean_us - stamp_kernel_us (stamp to stamp in a stamps-only replay): an upper bound "
+                                  "of the per-launch device time once the replay is under way (a stamp kernel between two step kernels "
+                                  "costs more than between two stamps); us[0] carries the replay's cold start"}
 
     # ---- after the timed region: episode returns from the trajectories the timed steps wrote ---------
     # (the only cross-GPU exchange: one all_gather of int8 per-lane returns + a 3-bin all_reduce)
@@ -497,7 +515,7 @@ def main():
                          "bound_note": "bytes counted at the L2<->fabric boundary (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits "
                                        "are included, and the ~%d MB working set of a run fits the 256 MB Infinity Cache when K is small"
                                        % ((12 * N + 7 * N * K) >> 20),
-                         "kernel": "soccer::step_kernel_swar<0, %s, false, 1>" % ("true" if args.slip else "false"),   # as rocprofv3 prints it
+                         "kernel": "soccer::step_kernel_swar<0, %s, false, 1>" % ("2" if args.slip else "0"),   # as rocprofv3 prints it (slips the table form does not cover: 1)
                          "frac_from": "ms_per_step (host wall clock, the clock `value` uses)",
                          "achieved_device": achieved_dev, "frac_device": achieved_dev / HBM_PEAK_GBPS,
                          "launch_us": launch_s * 1e6, "device_region_us": ev_ms * 1e3,
