@@ -1468,8 +1468,8 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int st = sb + k; st = st < 0 ? 0 : st; st = st < IO.n_steps ? st : IO.n_steps - 1;
-            if (load_a) nx[2 * k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + (uint32_t)i0));
-            if (load_b) nx[2 * k + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + (uint32_t)i0));
+            if (load_a) nx[2 * k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + i0));
+            if (load_b) nx[2 * k + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + i0));
         }
     };
     if (STAGED) fetch(-(int)((uint32_t)tick0 & 7u));
