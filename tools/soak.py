@@ -14,7 +14,7 @@ print("soak seed %d" % soak_seed, flush=True)
 rng = np.random.default_rng(soak_seed)
 pitches = [(5, 4), (6, 4), (7, 5), (9, 6), (11, 7), (5, 5), (8, 4), (6, 6), (13, 9)]
 slips = [0.0, 0.0, 0.2, 0.1, 0.3, 0.5, 0.9, 1.0, 0.05, 1 / 3, 0.25]
-t0 = time.time(); rounds = 0; lanes_steps = 0
+t0 = time.time(); rounds = 0; lanes_steps = 0; last_note = t0
 while time.time() - t0 < budget:
     w, h = pitches[rng.integers(len(pitches))]; slip = slips[rng.integers(len(slips))]
     n = int(rng.choice([4, 64, 1000, 4096, 4099, 8192 + 4 * int(rng.integers(0, 50))]))
@@ -100,4 +100,7 @@ while time.time() - t0 < budget:
     finally:
         b.close()
     rounds += 1
+    if time.time() - last_note > 60:            # a progress line a minute (a silent GPU job is taken to be hung)
+        last_note = time.time()
+        print("  %.0f s: %d configurations, %.3g lane-steps" % (last_note - t0, rounds, lanes_steps), flush=True)
 print("soak ok: %d random configurations, %.3g lane-steps compared bit for bit in %.0f s" % (rounds, lanes_steps, time.time() - t0))
