@@ -172,6 +172,9 @@ def main():
                     help="gloo: rehearse the multi-rank path on fewer GPUs than ranks (ranks share devices, "
                          "collectives go through host tensors); nccl (= RCCL over xGMI) is the real path")
     ap.add_argument("--no-vector-env", action="store_true", help="skip the VectorSoccerEnv(io='device') timing")
+    ap.add_argument("--action-loads", choices=["auto", "nt", "plain"], default="auto",
+                    help="how batched_step reads its action streams: nt = SOCCER_F_STREAM_ACTIONS, plain = the library default, "
+                         "auto = nt when the synthetic action trajectory exceeds 96 MB")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--selftest-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
@@ -221,8 +224,14 @@ def main():
     assert lane_hi - lane_lo == N
     KG = K - (K % 2)                             # a captured sequence holds an even number of launches;
                                                  # an odd K adds one eager launch inside the timed region
+    # The synthetic action trajectory is [max(K, W), 2, N] int8, read once per replay.  When it cannot stay in the 256 MB Infinity
+    # Cache between replays (K = 1000: 2 GB) the handle is told that its action streams stream in from HBM (SOCCER_F_STREAM_ACTIONS:
+    # non-temporal loads); a short sequence (the driver's K = 20: 40 MB) is re-read from the cache like the action buffer of an
+    # RL loop, the library's default (include/soccer_hip.h).  --action-loads overrides the choice.
+    act_bytes = max(K, W) * 2 * N
+    stream_actions = {"auto": act_bytes > (96 << 20), "nt": True, "plain": False}[args.action_loads]
     b = SoccerBatch(N, 5, 4, args.slip, seed=0, autoreset=True, device=dev_index,
-                    lane_offset=lane_lo, envs_per_thread=args.envs_per_thread, step_stats=False)
+                    lane_offset=lane_lo, envs_per_thread=args.envs_per_thread, step_stats=False, stream_actions=stream_actions)
 
     # synthetic inputs, resident in HBM before the timed region: uniform-random joint actions for
     # every step; outputs stream into [K, N] trajectory buffers (nothing is cached or skipped)
@@ -455,7 +464,8 @@ def main():
                 ("full", True, 31, "info=True: + final_observation, prob_code (info[agent]['p'] computed on access), int8 reward, episode histogram"),
                 ("lean", False, 23, "info=False: observations, player_a's float32 reward (player_b's = its negation, on access), terminated, truncated, _final_observation")):
             with torch.cuda.device(dev):
-                v = VectorSoccerEnv(N, slip_prob=args.slip, seed=0, io="device", device=dev_index, info=info)
+                v = VectorSoccerEnv(N, slip_prob=args.slip, seed=0, io="device", device=dev_index, info=info,
+                                    stream_actions=stream_actions)      # (it walks the same action trajectory)
                 v.reset()
                 KV = max(200, min(K, 1000))
                 pairs = [{"player_a": acts[k % KA, 0], "player_b": acts[k % KA, 1]} for k in range(KV)]
@@ -509,7 +519,8 @@ def main():
                                    "uniform-random joint actions, auto-reset, int8 SoA state, %s launches"
                                    % (N, world, args.slip, args.mode),
                        "lanes_per_gpu": N, "global_lanes": world * N, "slip_prob": args.slip,
-                       "parallelism": "independent lane shards x%d" % world},
+                       "parallelism": "independent lane shards x%d" % world,
+                       "action_loads": "%s (%s; action trajectory %d MB)" % ("non-temporal" if stream_actions else "plain", args.action_loads, act_bytes >> 20)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "bound_note": "bytes counted at the L2<->fabric boundary (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits "

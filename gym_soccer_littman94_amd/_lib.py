@@ -14,6 +14,7 @@ F_AUTORESET = 1
 F_NULL_STREAM = 2
 F_HOST_MAPPED = 4
 F_STEP_STATS = 8
+F_STREAM_ACTIONS = 16
 
 
 class SoccerHipError(RuntimeError):

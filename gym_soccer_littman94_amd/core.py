@@ -81,9 +81,12 @@ class SoccerBatch:
     """
 
     def __init__(self, n_lanes, width=5, height=4, slip_prob=0.0, seed=0, autoreset=False,
-                 max_steps=100, device=0, lane_offset=0, stream=None, envs_per_thread=0, host_mapped=False, step_stats=True):
+                 max_steps=100, device=0, lane_offset=0, stream=None, envs_per_thread=0, host_mapped=False, step_stats=True,
+                 stream_actions=False):
         """step_stats: batched_step also feeds the episode histogram (~5 % of a launch; on by default here,
         off in the raw C ABI).
+        stream_actions: batched_step reads its action streams with the non-temporal hint (SOCCER_F_STREAM_ACTIONS: action data
+        that is walked through once and does not fit the Infinity Cache).
         stream: None -> the handle creates its own HIP stream; an integer hipStream_t -> enqueue on
         that stream (0 = the device's default/null stream, which is what torch's default stream is)."""
         self.lib = _lib.load()
@@ -93,7 +96,8 @@ class SoccerBatch:
                      slip_prob=float(slip_prob), max_steps=int(max_steps), device=int(device),
                      seed=int(seed) & 0xFFFFFFFFFFFFFFFF, lane_offset=int(lane_offset),
                      flags=(_lib.F_AUTORESET if autoreset else 0) | (_lib.F_NULL_STREAM if stream == 0 else 0) |
-                     (_lib.F_HOST_MAPPED if host_mapped else 0) | (_lib.F_STEP_STATS if step_stats else 0),
+                     (_lib.F_HOST_MAPPED if host_mapped else 0) | (_lib.F_STEP_STATS if step_stats else 0) |
+                     (_lib.F_STREAM_ACTIONS if stream_actions else 0),
                      envs_per_thread=int(envs_per_thread), stream=stream or None)
         h = C.c_void_p()
         _lib.check(self.lib, None, self.lib.soccer_create(C.byref(cfg), C.byref(h)))

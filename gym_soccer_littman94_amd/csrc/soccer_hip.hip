@@ -449,7 +449,8 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
             const dim3 gh(static_cast<unsigned>(((cn >> 2) + kBlock - 1) / kBlock));
             SwarParams Q{h->swar_c, P.key0, P.key1, P.lane_offset + c0, 0ull, last ? P.tick_out : nullptr, P.misuse,
                          P.step_stats ? P.hist : nullptr, P.hist_mask,
-                         h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_slip_step_lut, P.policy_a, P.policy_b,
+                         h->slip_c, reinterpret_cast<const swar::Quad*>(P.sub), h->d_slip_step_lut,
+                         (h->cfg.flags & SOCCER_F_STREAM_ACTIONS) ? 1u : 0u, P.policy_a, P.policy_b,
                          off(io.obs, c0), off(io.reward, c0), off(io.terminated, c0), off(io.truncated, c0), off(io.prob_code, c0),
                          off(io.final_obs, c0), off(io.reward_a_f32, c0), off(io.reward_b_f32, c0), off(io.finished, c0),
                          off(io.last_return, c0)};

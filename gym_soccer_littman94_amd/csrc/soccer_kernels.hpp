@@ -953,6 +953,7 @@ struct SwarParams {
     unsigned long long* hist; uint32_t hist_mask;   // OUT == 2: episode histogram slots (SOCCER_F_STEP_STATS), or nullptr
     swar::SlipConsts L; const swar::Quad* sub;   // SLIPM == 1: integer cumulative weights / the nine rows of quarter thresholds
     const uint32_t* slip_lut;               // SLIPM == 2: SlipTables::lut_step (kSlipStepBuckets bytes), then T (kSlipThresholds words)
+    uint32_t act_stream;                    // SOCCER_F_STREAM_ACTIONS: the action streams are read with the non-temporal hint
     const int8_t* policy_a; const int8_t* policy_b;   // POLICY: the fixed side's int8[nS] policy (the other is nullptr)
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs;                          // OUT == 2
@@ -1020,14 +1021,31 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
     const bool fetch = SLIPM == 2 ? true : active;
     const uint32_t l0 = SLIPM == 2 ? (active ? i0 : (uint32_t)Q.first) : i0;
     if (fetch) {
-        S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp, l0)));
-        S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + state_stride, l0)));
-        S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 2 * state_stride, l0)));
-        S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 3 * state_stride, l0)));
-        S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 4 * state_stride, l0)));
-        S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 5 * state_stride, l0)));
-        if (!POLICY || !Q.policy_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_a, l0)));
-        if (!POLICY || !Q.policy_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_b, l0)));
+        // The action streams first, by plain loads unless the caller asked for the non-temporal hint (include/soccer_hip.h): buffers
+        // written or read a few steps ago are served from the Infinity Cache, and a non-temporal load gives that up — 0.2 us per
+        // launch at 2^20 lanes — while action data streaming in from HBM is 0.4 us per launch faster with the hint (DESIGN.md
+        // 4.3).  Both arms issue the same number of loads, so the waits below still count on the order.
+        const bool ld_a = !POLICY || !Q.policy_a, ld_b = !POLICY || !Q.policy_b;
+        // (each block gets the offset through an empty asm of its own: instruction selection works a block at a time and only
+        // turns base + offset into SGPR-base addressing when it sees the addition in the block of the access)
+        if (Q.act_stream) {
+            uint32_t la = l0; asm("" : "+v"(la));
+            if (ld_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_a, la)));
+            if (ld_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(act_b, la)));
+        } else {
+            // (written as wavefront-scope relaxed atomic loads — plain global_load_dword instructions — because the optimiser
+            // merges two arms that differ in nothing but the non-temporal hint, and drops the hint)
+            uint32_t la = l0; asm("" : "+v"(la));
+            if (ld_a) aa = __hip_atomic_load(reinterpret_cast<const uint32_t*>(AT(act_a, la)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (ld_b) ab = __hip_atomic_load(reinterpret_cast<const uint32_t*>(AT(act_b, la)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        uint32_t ls = l0; asm("" : "+v"(ls));
+        S.ra = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp, ls)));
+        S.ca = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + state_stride, ls)));
+        S.rb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 2 * state_stride, ls)));
+        S.cb = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 3 * state_stride, ls)));
+        S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 4 * state_stride, ls)));
+        S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 5 * state_stride, ls)));
     }
     // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
     const unsigned long long tick = tick_in ? *tick_in : tick_val;

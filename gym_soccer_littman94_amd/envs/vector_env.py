@@ -90,7 +90,8 @@ class VectorSoccerEnv:
 
     def __init__(self, num_envs, width=5, height=4, slip_prob=0.0, seed=0, autoreset=True,
                  device=0, lane_offset=0, max_episode_steps=100, io="numpy", strict=True,
-                 envs_per_thread=0, player_a_policy=None, player_b_policy=None, copy=True, float_rewards=True, info=True):
+                 envs_per_thread=0, player_a_policy=None, player_b_policy=None, copy=True, float_rewards=True, info=True,
+                 stream_actions=False):
         assert io in ("numpy", "device"), "io must be 'numpy' or 'device'"
         assert not (player_a_policy is not None and player_b_policy is not None), \
             "Both players cannot have a policy. At least one must be None."
@@ -108,7 +109,8 @@ class VectorSoccerEnv:
             stream = torch.cuda.current_stream(self._dev).cuda_stream   # results are ordered with torch work
         self._batch = SoccerBatch(self.num_envs, width, height, slip_prob, seed=seed, autoreset=autoreset,
                                   max_steps=max_episode_steps, device=device, lane_offset=lane_offset,
-                                  stream=stream, envs_per_thread=envs_per_thread, step_stats=self.info)
+                                  stream=stream, envs_per_thread=envs_per_thread, step_stats=self.info,
+                                  stream_actions=stream_actions)    # (SOCCER_F_STREAM_ACTIONS: see SoccerBatch)
         b = self._batch
         self.width, self.height, self.slip_prob = width + 2, height, slip_prob
         self.nS, self.nA = b.nS, b.nA

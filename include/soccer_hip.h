@@ -78,6 +78,11 @@ extern "C" {
                                     default: it costs ~5 % of a launch.  batched_rollout always counts. */
 #define SOCCER_F_HOST_MAPPED 4u  /* small handles (single-env facade): state and staging live in pinned host memory
                                     the GPU reads/writes in place, so the *_host calls and state access copy nothing */
+#define SOCCER_F_STREAM_ACTIONS 16u /* batched_step reads its action streams with the non-temporal hint: for callers that
+                                    walk through action data larger than the Infinity Cache once (long pre-generated
+                                    trajectories).  Unset (default): plain loads, which is faster when the buffers a step
+                                    reads were written or read a few steps ago (the loop of an RL agent; a short captured
+                                    sequence that is replayed) and slower when they stream in from HBM. */
 
 /* actions (soccer_simultaneous_env.py:8-12); moves are (dcol,drow) (:24-30) */
 #define SOCCER_NOOP  0

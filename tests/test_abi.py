@@ -58,6 +58,19 @@ int main(void) {
                    C.sizeof(Sc), Sc.act_a.offset, Sc.obs.offset, Sc.u_step.offset, Sc.u_reset.offset]
 
 
+def test_flag_and_error_constants_match_header():
+    """the cfg.flags bits and error codes of the Python wrapper are the header's #defines"""
+    text = open(os.path.join(ROOT, "include", "soccer_hip.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SOCCER_(F_[A-Z_]+|E_[A-Z_]+|OK)\s+(-?\d+)u?", text)}
+    assert {k: v for k, v in defs.items() if k.startswith("F_")} == {
+        "F_AUTORESET": _lib.F_AUTORESET, "F_NULL_STREAM": _lib.F_NULL_STREAM, "F_HOST_MAPPED": _lib.F_HOST_MAPPED,
+        "F_STEP_STATS": _lib.F_STEP_STATS, "F_STREAM_ACTIONS": _lib.F_STREAM_ACTIONS}
+    flags = [v for k, v in defs.items() if k.startswith("F_")]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)        # distinct single bits
+    for name in ("E_INVALID", "E_HIP", "E_NOMEM", "E_STATE", "OK"):
+        assert defs[name] == getattr(_lib, name)
+
+
 @pytest.mark.parametrize("kw,msg", [
     (dict(width=4), "Width must be at least 5"),
     (dict(height=3), "Height must be at least 4"),

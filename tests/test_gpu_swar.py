@@ -672,3 +672,29 @@ def test_both_slip_selections_of_the_single_step_agree(slip, monkeypatch):
     _state_equal(b1, o); _state_equal(b2, o)
     np.testing.assert_array_equal(b1.stats()[0], b2.stats()[0])
     b1.close(); b2.close()
+
+
+@pytest.mark.parametrize("slip,fixed", [(0.0, None), (0.2, None), (0.0, "player_b"), (0.2, "player_a")])
+def test_action_streams_with_the_non_temporal_hint(slip, fixed):
+    """SOCCER_F_STREAM_ACTIONS only changes how step_kernel_swar reads its action streams (non-temporal instead of plain loads:
+    two arms of the kernel): same seed, same actions -> the same streams as a default handle and as the oracle."""
+    n = 8192 + 4 * 11
+    rng = np.random.default_rng(41)
+    b1 = SoccerBatch(n, 5, 4, slip, seed=6, autoreset=True, step_stats=True)
+    b2 = SoccerBatch(n, 5, 4, slip, seed=6, autoreset=True, step_stats=True, stream_actions=True)
+    o = Oracle(5, 4, slip, n=n, seed=6, autoreset=True)
+    policy = rng.integers(0, 5, o.nS).astype(np.int8)
+    if fixed:
+        b1.set_policy(fixed, policy); b2.set_policy(fixed, policy)
+    io1, io2 = _IO(b1, True), _IO(b2, True)
+    b1.reset(); b2.reset(); cur = o.reset()
+    for k in range(50):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        if fixed == "player_a": a[0] = policy[cur]
+        if fixed == "player_b": a[1] = policy[cur]
+        c = o.step(a[0], a[1])
+        for io in (io1, io2):
+            _check(io.step(None if fixed == "player_a" else a[0], None if fixed == "player_b" else a[1]), c, k)
+        cur = c["obs"]
+    _state_equal(b1, o); _state_equal(b2, o)
+    b1.close(); b2.close()
