@@ -1477,6 +1477,9 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     // step took 1.5 us of which the SIMD was busy 1.1).  Instead the action dwords of eight steps — the ticks of one
     // Philox block — are fetched a block ahead into registers, parked in the thread's sixteen private LDS dwords at
     // the block boundary (the one wait per eight steps) and read back per step by ds_read, which counts separately.
+    // Plain loads, not non-temporal ones: re-read or streamed, the action rows come in faster without the hint (T = 100, 2^20
+    // lanes: 7.0 - 7.3 against 6.5 - 6.9 x 10^11 env-steps/s when the 200 MB block is re-read, 6.4 against 6.35 when six blocks are
+    // visited in turn; tools/labs/rollout_stream_lab.py) — unlike the single step's (step_kernel_swar, SOCCER_F_STREAM_ACTIONS).
     uint32_t aa = 0u, ab = 0u;
     uint32_t nx[16];                                                    // STAGED: the next block's action dwords, in flight
 #pragma unroll
@@ -1486,14 +1489,14 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int st = sb + k; st = st < 0 ? 0 : st; st = st < IO.n_steps ? st : IO.n_steps - 1;
-            if (load_a) nx[2 * k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + i0));
-            if (load_b) nx[2 * k + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + i0));
+            if (load_a) nx[2 * k] = *reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + i0);
+            if (load_b) nx[2 * k + 1] = *reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + i0);
         }
     };
     if (STAGED) fetch(-(int)((uint32_t)tick0 & 7u));
     else {
-        if (load_a) aa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + i0));
-        if (load_b) ab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + i0));
+        if (load_a) aa = *reinterpret_cast<const uint32_t*>(IO.act_a + i0);
+        if (load_b) ab = *reinterpret_cast<const uint32_t*>(IO.act_b + i0);
     }
     // the observation of the current tuple (goal tuples: 0), carried along when an action depends on it
     uint32_t s_lo = 0u, s_hi = 0u;
@@ -1525,8 +1528,8 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             if (load_a) aa = act_lds[(2u * t) * kBlock];
             if (load_b) ab = act_lds[(2u * t + 1u) * kBlock];
         } else if (s + 1 < IO.n_steps) {                                // DYNM == 3: prefetch the next step's actions
-            if (load_a) naa = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_a + (long long)(s + 1) * IO.act_stride + i0));
-            if (load_b) nab = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.act_b + (long long)(s + 1) * IO.act_stride + i0));
+            if (load_a) naa = *reinterpret_cast<const uint32_t*>(IO.act_a + (long long)(s + 1) * IO.act_stride + i0);
+            if (load_b) nab = *reinterpret_cast<const uint32_t*>(IO.act_b + (long long)(s + 1) * IO.act_stride + i0);
         }
         uint32_t a4 = aa, b4 = ab;
         if (DYN) {
