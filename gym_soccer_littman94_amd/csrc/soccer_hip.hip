@@ -603,7 +603,19 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                 RS.act_off = (uint32_t)(smem / sizeof(uint32_t));
                 smem += 16 * kBlock * sizeof(uint32_t);
             }
-            const uint64_t groups = P.n >> 2;
+            // The kernel's byte offsets are 32-bit: a handle beyond kSwarLaunchLanes lanes is rolled out part by part (lanes never
+            // interact), every part over the same ticks, each handed its piece of every stream; the last one publishes the tick.
+            const RolloutSwar RS0 = RS; const RolloutIO io0 = io;
+            for (unsigned long long c0 = 0; c0 < n4; c0 += h->swar_launch_lanes) {
+            const unsigned long long cn = std::min<unsigned long long>(h->swar_launch_lanes, n4 - c0);
+            RS = RS0; io = io0;
+            RS.state = RS0.state + P.first + c0; RS.first = 0ull; RS.n = cn; RS.lane_offset = RS0.lane_offset + P.first + c0;
+            if (c0 + cn < n4) RS.tick_out = nullptr;
+            const unsigned long long lane0 = P.first + c0;
+            io.act_a = off(io0.act_a, lane0); io.act_b = off(io0.act_b, lane0); io.obs = off(io0.obs, lane0); io.reward = off(io0.reward, lane0);
+            io.terminated = off(io0.terminated, lane0); io.truncated = off(io0.truncated, lane0);
+            io.return_sum = off(io0.return_sum, lane0); io.episode_count = off(io0.episode_count, lane0);
+            const uint64_t groups = cn >> 2;
             uint64_t blocks = (groups + kBlock - 1) / kBlock;
             if (blocks > (uint64_t)h->grid_cap) blocks = h->grid_cap;
             const dim3 g((unsigned)blocks), bl(kBlock);
@@ -622,6 +634,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
 #undef LAUNCH_D
 #undef LAUNCH_S
 #undef LAUNCH_G
+            }
             if (n4 < n_all) {
                 KernelParams Q = h->P;
                 Q.tick_in = P.tick_in; Q.tick_out = nullptr;      // the main launch publishes the tick

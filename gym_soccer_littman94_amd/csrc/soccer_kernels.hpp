@@ -1451,7 +1451,7 @@ template <int DYNM, int SLIPM, bool GENERAL, int GEO>
 __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const SlipSrc& slip,
                                                    const uint2* mix_a_in, const uint2* mix_b_in, const int8_t* pol_a_in, const int8_t* pol_b_in,
                                                    uint32_t* act_lds,
-                                                   unsigned long long i0, unsigned long long tick0, swar::Group& S,
+                                                   uint32_t i0, unsigned long long tick0, swar::Group& S,
                                                    uint32_t& fin_tot, uint32_t& nz_tot, uint32_t& neg_tot,
                                                    uint32_t (&acc)[4], uint32_t& frozen_any, uint32_t& bad_any) {
     constexpr bool DYN = DYNM != 0;
@@ -1486,11 +1486,20 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     for (int k = 0; k < 16; ++k) nx[k] = 0u;
     // issue the loads of the block whose tick-0 step is `sb` (steps outside the rollout are clamped: a harmless re-read)
     auto fetch = [&](int sb) {
+        uint32_t f0 = i0; asm volatile("" : "+v"(f0));
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int st = sb + k; st = st < 0 ? 0 : st; st = st < IO.n_steps ? st : IO.n_steps - 1;
-            if (load_a) nx[2 * k] = *reinterpret_cast<const uint32_t*>(IO.act_a + (long long)st * IO.act_stride + i0);
-            if (load_b) nx[2 * k + 1] = *reinterpret_cast<const uint32_t*>(IO.act_b + (long long)st * IO.act_stride + i0);
+            // The step's rows are held in scalar registers: passed through an empty asm, else the optimiser folds the row offset
+            // into the per-thread address and pays a 64-bit vector multiply-add per load (16 per block of eight steps).  What
+            // comes out of an asm statement is a generic pointer unless its type says global memory (flat_load otherwise).
+            typedef const uint8_t __attribute__((address_space(1)))* gbytes;
+            typedef const uint32_t __attribute__((address_space(1)))* gwords;
+            gbytes row_a = (gbytes)(IO.act_a + (long long)st * IO.act_stride);
+            gbytes row_b = (gbytes)(IO.act_b + (long long)st * IO.act_stride);
+            asm volatile("" : "+s"(row_a)); asm volatile("" : "+s"(row_b));
+            if (load_a) nx[2 * k] = *(gwords)(row_a + f0);
+            if (load_b) nx[2 * k + 1] = *(gwords)(row_b + f0);
         }
     };
     if (STAGED) fetch(-(int)((uint32_t)tick0 & 7u));
@@ -1583,12 +1592,16 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         }
         swar::step4<GENERAL, false, SLIP, GEO, TRUSTED>(C, S, a4, b4, sa, sb, cls4, rnd, o);
         s_lo = o.obs_lo; s_hi = o.obs_hi;
-        const long long off = (long long)s * IO.out_stride + (long long)i0;
+        // the step's row of every stream as a uniform base (scalar registers) + this thread's 32-bit byte offset: stores of the
+        // form v_off, data, s[base] (the offset passes through an empty asm per step, else the optimiser keeps one 64-bit
+        // per-thread address per stream across the loop and adds the row to it with vector instructions)
+        const long long row = (long long)s * IO.out_stride;
+        uint32_t j0 = i0; asm volatile("" : "+v"(j0));
         if (IO.obs) __builtin_nontemporal_store((unsigned long long)o.obs_lo | ((unsigned long long)o.obs_hi << 32),
-                                                reinterpret_cast<unsigned long long*>(IO.obs + off));
-        if (IO.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(IO.reward + off));
-        if (IO.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(IO.terminated + off));
-        if (IO.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(IO.truncated + off));
+                                                reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(IO.obs + row) + (j0 << 1)));
+        if (IO.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(IO.reward + row) + j0));
+        if (IO.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(IO.terminated + row) + j0));
+        if (IO.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(IO.truncated + row) + j0));
         // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends an episode
         fin_loc += (uint32_t)__builtin_popcount(o.finished & swar::K80);
         if (GENERAL) { nz_loc += (uint32_t)__builtin_popcount(o.rew & swar::K01); neg_loc += (uint32_t)__builtin_popcount(o.rew & swar::K80); }
@@ -1652,13 +1665,14 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         __syncthreads();
     }
     const unsigned long long tick0 = *R.tick_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *R.tick_out = tick0 + (unsigned long long)IO.n_steps;
+    if (R.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *R.tick_out = tick0 + (unsigned long long)IO.n_steps;
     const unsigned long long groups = R.n >> 2;                      // the launch covers a multiple of 4 lanes
     uint32_t frozen_any = 0u, bad_any = 0u;
     uint32_t* act_lds = smem + R.act_off + threadIdx.x;              // this thread's sixteen dwords, kBlock apart
     for (unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; g < groups;
          g += (unsigned long long)gridDim.x * kBlock) {
-        const unsigned long long i0 = R.first + (g << 2);
+        // 32-bit byte offsets: the host hands the kernel at most kSwarLaunchLanes lanes at a time (like step_kernel_swar)
+        const uint32_t i0 = (uint32_t)R.first + ((uint32_t)g << 2);
         const uint8_t* sp = R.state + i0;
         swar::Group S;
         S.ra = *reinterpret_cast<const uint32_t*>(sp); S.ca = *reinterpret_cast<const uint32_t*>(sp + R.state_stride);

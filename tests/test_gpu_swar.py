@@ -698,3 +698,30 @@ def test_action_streams_with_the_non_temporal_hint(slip, fixed):
         cur = c["obs"]
     _state_equal(b1, o); _state_equal(b2, o)
     b1.close(); b2.close()
+
+
+@pytest.mark.parametrize("slip", [0.0, 0.2])
+def test_a_rollout_split_into_several_launches_is_the_same_rollout(slip, monkeypatch):
+    """rollout_swar_kernel addresses its streams with 32-bit byte offsets too: a handle beyond 2^30 lanes is rolled out part by
+    part (batched_rollout in soccer_hip.hip), every part over the same ticks, the last one publishing the tick.
+    SOCCER_SWAR_LAUNCH_LANES shrinks the part: 3 parts + a short one, streams in and four trajectories out, per-lane return sums
+    / episode counts, then sampled actions; the histogram; followed by single steps on the same ticks."""
+    monkeypatch.setenv("SOCCER_SWAR_LAUNCH_LANES", "4096")
+    n, T = 3 * 4096 + 1028, 37
+    b = SoccerBatch(n, 5, 4, slip, seed=29, autoreset=True, lane_offset=4 * 55, step_stats=True)
+    monkeypatch.delenv("SOCCER_SWAR_LAUNCH_LANES")
+    o = Oracle(5, 4, slip, n=n, seed=29, autoreset=True, lane_offset=4 * 55)
+    rng = np.random.default_rng(13)
+    b.reset(); o.reset()
+    acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
+    _rollout_vs_oracle(b, o, acts, T, n)
+    _rollout_vs_oracle(b, o, None, T, n, sample=True)
+    io = _IO(b, True)
+    for k in range(5):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        _check(io.step(a[0], a[1]), o.step(a[0], a[1]), k)
+    _state_equal(b, o)
+    hist, misuse = b.stats()
+    np.testing.assert_array_equal(hist, o.hist)
+    assert misuse == 0 and b.tick == o.tick
+    b.close()
