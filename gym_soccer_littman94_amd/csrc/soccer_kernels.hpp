@@ -1582,7 +1582,10 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         } else {
             if (t == 0u && s != 0) {
                 const unsigned long long bt = tick >> 3;
-                const Philox4 b = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), R.key0, R.key1);
+                // (the key through an empty asm: the ten round keys are then derived here, by scalar adds every eighth step, instead
+                // of living in twenty scalar registers across the loop — which spilled to vector lanes and came back by v_readlane)
+                uint32_t k0 = R.key0, k1 = R.key1; asm volatile("" : "+s"(k0), "+s"(k1));
+                const Philox4 b = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), k0, k1);
                 swar::transpose4(b.w[0], b.w[1], b.w[2], b.w[3], p0, p1, p2, p3);
             }
             rnd = swar::rand_pair(C.isd_shift, t, p0);
