@@ -31,6 +31,13 @@ if slipk:
     for r in csv.DictReader(open(slipk[0])):
         if 'soccer::' in r['Name']:
             print("%-100s calls %5s avg %10.1f min %8s max %8s" % (r['Name'][:100], r['Calls'], float(r['AverageNs']), r['MinNs'], r['MaxNs']))
+k20 = glob.glob(src + '/kt_k20/runc/*_kernel_stats.csv') + glob.glob(src + '/kt_k20/*kernel_stats.csv')
+if k20:
+    shutil.copy(k20[0], 'profiles/%s_kernel_stats_driver_shape.csv' % tag)
+    print("-- the driver's command, --steps 20 --warmup 5 (kt_k20):")
+    for r in csv.DictReader(open(k20[0])):
+        if 'soccer::' in r['Name']:
+            print("%-100s calls %5s avg %10.1f min %8s max %8s" % (r['Name'][:100], r['Calls'], float(r['AverageNs']), r['MinNs'], r['MaxNs']))
 for extra in ('bench_unprofiled.json', 'bench_driver_shape.json', 'bench_slip_unprofiled.json'):
     if _os.path.exists(src + '/' + extra):
         l2 = open(src + '/' + extra).read().strip().split('\n')[-1]

@@ -5,6 +5,7 @@
 #   fetch / write   FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, rocprofv3 PMC slots)
 #   sq1 / sq2       SQ instruction / wait counters
 #   kt_slip / sq_slip   kernel trace and instruction counters of the same commands at slip 0.2
+#   kt_k20   kernel trace of the driver's command (--steps 20 --warmup 5)
 # Counters are collected with --kernel-trace only (never with the runtime / hip trace domains).
 set -e
 TAG=${1:-r02}
@@ -34,6 +35,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_slip" -o runc -
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d "$OUT/sq_slip" -o runc -- python3 "$B" --slip 0.2 $SQ_ARGS > "$OUT/sq_slip.json" 2> "$OUT/sq_slip.err"
 python3 "$B" --slip 0.2 --steps 1000 --warmup 50 --no-cpu-baseline --no-vector-env > "$OUT/bench_slip_unprofiled.json" 2>/dev/null
 echo "slip done"
+# the driver's own command (--steps 20 --warmup 5: plain action loads, a 146 MB working set) under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_k20" -o runc -- python3 "$B" --steps 20 --warmup 5 --no-cpu-baseline --rollout 0 --no-vector-env > "$OUT/bench_k20_profiled.json" 2> "$OUT/kt_k20.err"
+echo "kt_k20 done"
 # un-profiled reference run of the same command as kt (a profiled run clocks lower)
 python3 "$B" --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/bench_unprofiled.json" 2>/dev/null
 python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_driver_shape.json" 2>/dev/null
