@@ -21,7 +21,8 @@ while time.time() - t0 < budget:
     off = int(rng.integers(0, 1 << 40)) & ~3 if rng.random() < 0.8 else int(rng.integers(0, 1 << 20))
     seed = int(rng.integers(0, 1 << 62)); autoreset = bool(rng.random() < 0.7)
     ms = int(rng.choice([100, 100, 17, 127, 200]))
-    b = SoccerBatch(n, w, h, slip, seed=seed, autoreset=autoreset, lane_offset=off, max_steps=ms, step_stats=bool(rng.random() < 0.5))
+    b = SoccerBatch(n, w, h, slip, seed=seed, autoreset=autoreset, lane_offset=off, max_steps=ms, step_stats=bool(rng.random() < 0.5),
+                    stream_actions=bool(rng.random() < 0.3))           # (both arms of the step kernel's action loads)
     o = Oracle(w, h, slip, n=n, seed=seed, autoreset=autoreset, lane_offset=off, max_steps=ms)
     tag = "pitch %dx%d slip %g n %d off %d seed %d autoreset %s max_steps %d" % (w, h, slip, n, off, seed, autoreset, ms)
     try:
