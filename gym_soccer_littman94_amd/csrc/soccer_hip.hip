@@ -74,7 +74,7 @@ struct soccer_handle {
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
     bool stamp_poll = false;                // soccer_timer_read may watch the closing stamp of the last soccer_graph_launch change ...
     unsigned long long stamp_prev = 0;      // ... from this value (what the slot held when the replay was enqueued)
-    unsigned long long swar_launch_lanes = kSwarLaunchLanes;   // lanes per step_kernel_swar launch (SOCCER_SWAR_LAUNCH_LANES: tests of the split)
+    unsigned long long swar_launch_lanes = kSwarLaunchLanes;   // lanes per step_kernel_swar / rollout_swar_kernel launch (SOCCER_SWAR_LAUNCH_LANES: tests of the split)
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;

@@ -1205,6 +1205,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel_swar(const ResetSwar R) {
     }
     const unsigned long long tick = *R.tick_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *R.tick_out = tick + 1ull;
+    if (!MASKED) {      // what a reset of every lane writes without a draw — both columns, the timestep — leaves before the Philox block
+        *reinterpret_cast<uint32_t*>(sp + R.state_stride) = R.C.isd_ca4; *reinterpret_cast<uint32_t*>(sp + 3 * R.state_stride) = R.C.isd_cb4;
+        *reinterpret_cast<uint32_t*>(sp + 5 * R.state_stride) = 0u;
+    }
     const unsigned long long q = (R.lane_offset + i0) >> 2;
     const unsigned long long bt = block_tick<SLIP>(tick);
     const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), R.key0, R.key1);
@@ -1212,9 +1216,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel_swar(const ResetSwar R) {
     const swar::Rand4 rnd = SLIP ? swar::rand_words(R.C.isd_shift, blk.w[0], blk.w[1], blk.w[2], blk.w[3])
                                  : swar::rand_nibble(R.C.isd_shift, (uint32_t)tick & 7u, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
     swar::reset4<MASKED>(R.C, S, mask4, rnd, o_lo, o_hi);
-    *reinterpret_cast<uint32_t*>(sp) = S.ra; *reinterpret_cast<uint32_t*>(sp + R.state_stride) = S.ca;
-    *reinterpret_cast<uint32_t*>(sp + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sp + 3 * R.state_stride) = S.cb;
-    *reinterpret_cast<uint32_t*>(sp + 4 * R.state_stride) = S.ps; *reinterpret_cast<uint32_t*>(sp + 5 * R.state_stride) = S.tt;
+    *reinterpret_cast<uint32_t*>(sp) = S.ra; *reinterpret_cast<uint32_t*>(sp + 2 * R.state_stride) = S.rb;
+    *reinterpret_cast<uint32_t*>(sp + 4 * R.state_stride) = S.ps;
+    if (MASKED) {
+        *reinterpret_cast<uint32_t*>(sp + R.state_stride) = S.ca; *reinterpret_cast<uint32_t*>(sp + 3 * R.state_stride) = S.cb;
+        *reinterpret_cast<uint32_t*>(sp + 5 * R.state_stride) = S.tt;
+    }
     if (R.obs) *reinterpret_cast<uint2*>(R.obs + i0) = make_uint2(o_lo, o_hi);
 }
 
