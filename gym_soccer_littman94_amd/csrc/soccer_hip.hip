@@ -639,7 +639,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
                 KernelParams Q = h->P;
                 Q.tick_in = P.tick_in; Q.tick_out = nullptr;      // the main launch publishes the tick
                 Q.first = n4; Q.n = n_all - n4;
-                launch_rollout<1>(h, Q, io);
+                launch_rollout<1>(h, Q, io0);           // (io0: the loop above left `io` offset to its last part; the per-lane kernel indexes by absolute lane)
             }
         } else switch (E) {
             case 8: launch_rollout<8>(h, P, io); break;

@@ -42,6 +42,8 @@ def lib():
         L.soc_oracle_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.soc_oracle_transitions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         L.soc_oracle_transitions.restype = C.c_int
+        L.soc_oracle_dump_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.soc_oracle_dump_table.restype = C.c_int64
         L.soc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.soc_oracle_batched_reset.argtypes = [C.c_void_p, C.c_int64, C.POINTER(_State), C.c_void_p,
                                                C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
@@ -123,6 +125,14 @@ class Oracle:
         if n < 0:
             raise KeyError(tuple(int(x) for x in st))
         return p[:n], ns[:n], r[:n], d[:n]
+
+    def dump_table(self):
+        """The complete transition relation in the canonical order of tests/golden/make_golden.py::table_digest:
+        rows int8[n, 15] (xa,ya,xb,yb,p, aa,ab, k, next tuple, reward, done), prob float64[n]."""
+        n = self.L.soc_oracle_dump_table(self.h, None, None, 0)
+        rows = np.zeros((n, 15), np.int8); prob = np.zeros(n, np.float64)
+        assert self.L.soc_oracle_dump_table(self.h, _p(rows), _p(prob), n) == n
+        return rows, prob
 
     def set_state(self, row_a, col_a, row_b, col_b, poss, t=None, needs_reset=None):
         self.row_a[:] = row_a; self.col_a[:] = col_a; self.row_b[:] = row_b; self.col_b[:] = col_b

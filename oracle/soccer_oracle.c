@@ -269,6 +269,30 @@ int soc_oracle_transitions(const soc_oracle* o, const int8_t st[5], int aa, int 
     return tl->n;
 }
 
+/* The whole table in the canonical order of tests/golden/make_golden.py (table_digest): ascending flat tuple index,
+ * aa, ab, list position k — the reference's own P_readable iteration order (:167-293).  rows: int8[n][15] =
+ * xa,ya,xb,yb,p, aa,ab, k, nxa,nya,nxb,nyb,np, reward, done.  Returns the row count; with rows == NULL only counts. */
+int64_t soc_oracle_dump_table(const soc_oracle* o, int8_t* rows, double* prob, int64_t capacity) {
+    int64_t n = 0;
+    for (int32_t f = 0; f < o->n_tuples; ++f) {
+        if (o->kind[f] == 0) continue;
+        int xa, ya, xb, yb, pp; unflat(o, f, &xa, &ya, &xb, &yb, &pp);
+        for (int ja = 0; ja < 25; ++ja) {
+            const trans_list* tl = &o->P[(size_t)f * 25 + ja];
+            for (int k = 0; k < tl->n; ++k, ++n) {
+                if (!rows) continue;
+                if (n >= capacity) return -1;
+                int8_t* r = rows + 15 * n;
+                int nxa, nya, nxb, nyb, np_; unflat(o, tl->ns[k], &nxa, &nya, &nxb, &nyb, &np_);
+                r[0] = xa; r[1] = ya; r[2] = xb; r[3] = yb; r[4] = pp; r[5] = ja / 5; r[6] = ja % 5; r[7] = k;
+                r[8] = nxa; r[9] = nya; r[10] = nxb; r[11] = nyb; r[12] = np_; r[13] = tl->r[k]; r[14] = (int8_t)tl->d[k];
+                prob[n] = tl->p[k];
+            }
+        }
+    }
+    return n;
+}
+
 /* categorical_sample (gym 0.26.2): argmax(cumsum(p) > u) */
 static int categorical_sample(const double* p, int n, double u) {
     double acc = 0.0;

@@ -26,8 +26,15 @@ What is dumped
   single_5x4_s{slip}_{agent}.npz  single-agent (fixed-opponent) transition table
   vi_5x4_s{slip}_{agent}_vs_{opp}.npz  the reference's value_iteration (utils/planners.py) on its own tables
 
+  digest_{W}x{H}_s{slip}.npz  for tables too large to commit (11x7 with slip: 3.4 M rows): the state
+                              classification + SHA-256 of the canonical full-table dump (table_digest below)
+                              + one 32-bit digest per state tuple to localise a mismatch
+  traj_5x4_s{slip}_seed0_10k.npz  BASELINE config 1 at its stated length (10 000 steps)
+
 Usage:  python tests/golden/make_golden.py                  (everything below 11x7)
         python tests/golden/make_golden.py one 11 7 0.0 4000   (one pitch: table + replay + reset)
+        python tests/golden/make_golden.py digest 11 7 0.2 4000   (one pitch: table DIGEST + replay + reset)
+        python tests/golden/make_golden.py traj10k              (the two 10 000-step trajectories)
 """
 import json
 import os
@@ -99,7 +106,25 @@ def slip_tag(s):
     return ("%g" % s).replace(".", "p")
 
 
-def dump_table(Env, width, height, slip):
+def table_digest(rows, prob):
+    """Canonical digest of a full transition table.  rows int8[n, 15] = xa,ya,xb,yb,p, aa,ab, k, nxa,nya,nxb,nyb,np, reward, done
+    in ascending (flat tuple index, aa, ab) order with k ascending (the reference's own P_readable iteration order), prob
+    float64[n].  Returns (sha256 hex of rows bytes + little-endian prob bytes, uint32 digest per state tuple in order of
+    appearance: the first four bytes of the SHA-256 of that tuple's rows + probs)."""
+    import hashlib
+    rows = np.ascontiguousarray(rows, dtype=np.int8); prob = np.ascontiguousarray(prob, dtype="<f8")
+    assert rows.ndim == 2 and rows.shape[1] == 15 and len(rows) == len(prob)
+    h = hashlib.sha256(); h.update(rows.tobytes()); h.update(prob.tobytes())
+    change = np.flatnonzero((np.diff(rows[:, :5].astype(np.int16), axis=0) != 0).any(axis=1)) + 1
+    bounds = np.concatenate([[0], change, [len(rows)]])
+    per = np.zeros(len(bounds) - 1, np.uint32)
+    for i in range(len(bounds) - 1):
+        s, e = bounds[i], bounds[i + 1]
+        per[i] = int.from_bytes(hashlib.sha256(rows[s:e].tobytes() + prob[s:e].tobytes()).digest()[:4], "little")
+    return h.hexdigest(), per
+
+
+def dump_table(Env, width, height, slip, digest_only=False):
     t0 = time.time()
     env = Env(width=width, height=height, slip_prob=slip)
     H, W = env.height, env.width
@@ -134,6 +159,25 @@ def dump_table(Env, width, height, slip):
                 probs.append(p)
     rows = np.asarray(rows, dtype=np.int8)
     probs = np.asarray(probs, dtype=np.float64)
+    if digest_only:
+        r = rows[rows[:, 7] == 0].astype(np.int64)
+        key = ((((r[:, 0] * W + r[:, 1]) * H + r[:, 2]) * W + r[:, 3]) * 2 + r[:, 4]) * 25 + r[:, 5] * 5 + r[:, 6]
+        assert (np.diff(key) > 0).all(), "the reference's iteration order is the canonical order"
+        sha, per = table_digest(rows, probs)
+        lens = np.diff(np.append(np.flatnonzero(rows[:, 7] == 0), len(rows)))
+        out = os.path.join(HERE, "digest_%dx%d_s%s.npz" % (width, height, slip_tag(slip)))
+        np.savez_compressed(
+            out, width=np.int32(width), height=np.int32(height), slip=np.float64(slip),
+            nS=np.int32(env.nS), nA=np.int32(env.nA), goal_rows=np.asarray(env.goal_rows, dtype=np.int8),
+            lut=lut, kind=kind, goal_value=goal_value,
+            isd_states=np.asarray([s for _, s in env.isd], dtype=np.int8),
+            isd_probs=np.asarray([p for p, _ in env.isd], dtype=np.float64),
+            n_rows=np.int64(len(rows)), sha256=np.bytes_(sha), tuple_digest=per,
+            list_length_hist=np.bincount(lens, minlength=37).astype(np.int64),
+            prob_sum=np.float64(probs.sum()), reference_ctor_seconds=np.float64(time.time() - t0))
+        print("  %s: %d rows (not stored), sha256 %s, nS=%d, %.1fs, %d KB" % (
+            os.path.basename(out), len(rows), sha[:16], env.nS, time.time() - t0, os.path.getsize(out) // 1024))
+        return env
     out = os.path.join(HERE, "table_%dx%d_s%s.npz" % (width, height, slip_tag(slip)))
     np.savez_compressed(
         out,
@@ -189,7 +233,7 @@ def dump_replay(env, width, height, slip, n, seed):
     print("  %s: %d vectors, %d KB" % (os.path.basename(out), n, os.path.getsize(out) // 1024))
 
 
-def dump_reset(env, width, height):
+def dump_reset(env, width, height, slip=None):
     us = [0.0, 0.2499, 0.25, 0.4999999, 0.5, 0.75, 0.99999, 1.0 - 2.0 ** -53] + \
         list(np.random.RandomState(5).random_sample(200))
     states = np.zeros((len(us), 5), np.int8); obs = np.zeros(len(us), np.uint16)
@@ -199,13 +243,13 @@ def dump_reset(env, width, height):
         o, info = env.reset()
         states[i] = env.state; obs[i] = o["player_a"]; p[i] = info["player_a"]["p"]
         assert env.timestep == 0 and env.needs_reset is False
-    out = os.path.join(HERE, "reset_%dx%d.npz" % (width, height))
-    np.savez_compressed(out, width=np.int32(width), height=np.int32(height),
+    out = os.path.join(HERE, "reset_%dx%d%s.npz" % (width, height, "" if slip is None else "_s" + slip_tag(slip)))
+    np.savez_compressed(out, width=np.int32(width), height=np.int32(height), slip=np.float64(slip or 0.0),
                         u=np.asarray(us, np.float64), state=states, obs=obs, p=p)
     print("  %s: %d vectors" % (os.path.basename(out), len(us)))
 
 
-def dump_traj(Env, slip, seed, n_steps):
+def dump_traj(Env, slip, seed, n_steps, tag=""):
     """MT19937-driven episodes through the real reset()/step() (BASELINE config 1 shape)."""
     env = Env(width=5, height=4, slip_prob=slip)
     rec = _RecordingRS(env.np_random)
@@ -227,7 +271,7 @@ def dump_traj(Env, slip, seed, n_steps):
         obs[k] = o["player_a"]; r_a[k] = r["player_a"]; r_b[k] = r["player_b"]
         done[k] = d["player_a"]; trunc[k] = tr["player_a"]; p[k] = info["player_a"]["p"]
         state[k] = env.state
-    out = os.path.join(HERE, "traj_5x4_s%s_seed%d.npz" % (slip_tag(slip), seed))
+    out = os.path.join(HERE, "traj_5x4_s%s_seed%d%s.npz" % (slip_tag(slip), seed, tag))
     np.savez_compressed(out, slip=np.float64(slip), seed=np.int64(seed), actions=actions,
                         first_obs=np.uint16(first_obs), u_first_reset=np.float64(u_first_reset),
                         obs=obs, reward_a=r_a, reward_b=r_b, terminated=done, truncated=trunc,
@@ -355,9 +399,31 @@ def main_one(w, h, s, nrep):
         dump_reset(env, w, h)
 
 
+def main_digest(w, h, s, nrep):
+    """A pitch whose full table is too large to commit (11x7 with slip, the reference's largest parametrisation
+    gym_soccer/tests/test_general.py:5-11 with the slip of its registration stub): digest + replay + reset."""
+    _install_gym_stand_in()
+    from gym_soccer.envs import SoccerSimultaneousEnv as Env
+    env = dump_table(Env, w, h, s, digest_only=True)
+    dump_replay(env, w, h, s, nrep, seed=1000 + w * 10 + h)
+    dump_reset(env, w, h, slip=s)
+
+
+def main_traj10k():
+    """BASELINE config 1 at its stated length: 10 000 uniform-random joint-action steps, reset(seed=0)."""
+    _install_gym_stand_in()
+    from gym_soccer.envs import SoccerSimultaneousEnv as Env
+    for s in (0.0, 0.2):
+        dump_traj(Env, s, 0, 10000, tag="_10k")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "planners":
         main_planners()
+    elif len(sys.argv) > 1 and sys.argv[1] == "digest":
+        main_digest(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 4000)
+    elif len(sys.argv) > 1 and sys.argv[1] == "traj10k":
+        main_traj10k()
     elif len(sys.argv) > 1 and sys.argv[1] == "one":
         main_one(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 4000)
     else:

@@ -46,7 +46,7 @@ def test_same_seed_reproduces_reference_trajectories(path):
     env = SoccerSimultaneousEnv(width=5, height=4, slip_prob=float(g["slip"]))
     obs, info = env.reset(seed=int(g["seed"]))
     assert obs['player_a'] == g["first_obs"] == obs['player_b'] and info['player_a']['p'] == 0.25
-    n = 600
+    n = len(g["obs"]) if path.endswith("_10k.npz") else 600       # _10k: BASELINE config 1 at its stated length, every step
     for k in range(n):
         if env.needs_reset:
             assert g["reset_before"][k]
@@ -263,6 +263,45 @@ def test_device_enumerated_transition_table_equals_reference_row_for_row(path):
     last = np.append(k[1:] == 0, True)
     np.testing.assert_array_equal(count[flat[last], ja[last]], k[last] + 1)
     np.testing.assert_array_equal(count[:, 0] < 0, g["kind"] == 0)
+    b.close()
+
+
+DIGESTS = sorted(glob.glob(os.path.join(GOLDEN, "digest_*.npz")))
+
+
+@pytest.mark.parametrize("path", DIGESTS, ids=[os.path.basename(p)[:-4] for p in DIGESTS])
+def test_device_enumerated_transition_table_hashes_to_the_reference_digest(path):
+    """Tables too large to commit (11x7 with slip_prob 0.2: 3.4 M rows): soccer_enumerate_transitions, brought into the
+    reference's own iteration order, must hash to what the reference's P_readable hashed to
+    (tests/golden/make_golden.py::table_digest; soccer_simultaneous_env.py:167-293, sizes of tests/test_general.py:5-11)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden import table_digest
+    from gym_soccer_littman94_amd import SoccerBatch
+    d = np.load(path)
+    w, h = int(d["width"]), int(d["height"]); W = w + 2
+    b = SoccerBatch(1, w, h, float(d["slip"]))
+    count, prob, nxt, rew, done = b.transitions()
+    lut, goal_value, isd = b.tables()
+    np.testing.assert_array_equal(lut, d["lut"]); np.testing.assert_array_equal(goal_value, d["goal_value"])
+    np.testing.assert_array_equal(isd, d["isd_states"]); assert b.nS == int(d["nS"])
+    np.testing.assert_array_equal(count[:, 0] < 0, d["kind"] == 0)
+    f, ja = np.nonzero(count > 0)                                      # ascending (flat tuple, joint action): the canonical order
+    c = count[f, ja]
+    assert int(c.sum()) == int(d["n_rows"])
+    np.testing.assert_array_equal(np.bincount(c, minlength=37), d["list_length_hist"])
+    F = np.repeat(f, c); JA = np.repeat(ja, c)
+    K = np.arange(len(F)) - np.repeat(np.cumsum(c) - c, c)
+
+    def unflat(x):
+        p = x & 1; x = x >> 1; yb = x % W; x //= W; xb = x % h; x //= h; ya = x % W; xa = x // W
+        return [xa, ya, xb, yb, p]
+    cols = unflat(F) + [JA // 5, JA % 5, K] + unflat(nxt[F, JA, K].astype(np.int64)) + [rew[F, JA, K], done[F, JA, K]]
+    rows = np.stack([np.asarray(x).astype(np.int8) for x in cols], axis=1)
+    sha, per = table_digest(rows, prob[F, JA, K])
+    bad = np.flatnonzero(per != d["tuple_digest"])
+    assert bad.size == 0, "first differing state tuple (in order of appearance): %d" % bad[0]
+    assert sha == d["sha256"].item().decode()
     b.close()
 
 

@@ -109,7 +109,7 @@ def test_replay_vectors_from_reference_step(path, epw):
 def test_reset_vectors_from_reference_reset(path):
     g = np.load(path)
     n = len(g["u"])
-    b = SoccerBatch(n, int(g["width"]), int(g["height"]), 0.0)
+    b = SoccerBatch(n, int(g["width"]), int(g["height"]), float(g["slip"]) if "slip" in g.files else 0.0)
     u = b.alloc(n, np.float64).upload(g["u"]); obs = b.alloc(n, np.uint16)
     b.reset(u_reset=u, obs=obs)
     s = b.get_state(); st = g["state"]

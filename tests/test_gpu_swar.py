@@ -707,7 +707,7 @@ def test_a_rollout_split_into_several_launches_is_the_same_rollout(slip, monkeyp
     SOCCER_SWAR_LAUNCH_LANES shrinks the part: 3 parts + a short one, streams in and four trajectories out, per-lane return sums
     / episode counts, then sampled actions; the histogram; followed by single steps on the same ticks."""
     monkeypatch.setenv("SOCCER_SWAR_LAUNCH_LANES", "4096")
-    n, T = 3 * 4096 + 1028, 37
+    n, T = 3 * 4096 + 1028 + 3, 37           # + 3: a ragged tail behind SEVERAL parts (the per-lane kernel, absolute lane indices)
     b = SoccerBatch(n, 5, 4, slip, seed=29, autoreset=True, lane_offset=4 * 55, step_stats=True)
     monkeypatch.delenv("SOCCER_SWAR_LAUNCH_LANES")
     o = Oracle(5, 4, slip, n=n, seed=29, autoreset=True, lane_offset=4 * 55)

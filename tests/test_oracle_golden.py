@@ -4,6 +4,7 @@ float64 probabilities, injected-uniform replays through the reference's step()/r
 MT19937-driven trajectories."""
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -11,10 +12,13 @@ import pytest
 from oracle.oracle import Oracle, philox4x32_10
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+from make_golden import table_digest          # the digest's definition lives next to the script that dumped it (imports nothing of the reference)
 TABLES = sorted(glob.glob(os.path.join(GOLDEN, "table_*.npz")))
 REPLAYS = sorted(glob.glob(os.path.join(GOLDEN, "replay_*.npz")))
 RESETS = sorted(glob.glob(os.path.join(GOLDEN, "reset_*.npz")))
 TRAJS = sorted(glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
+DIGESTS = sorted(glob.glob(os.path.join(GOLDEN, "digest_*.npz")))
 
 
 def _ids(paths):
@@ -23,6 +27,10 @@ def _ids(paths):
 
 def test_fixtures_present():
     assert len(TABLES) >= 8 and len(REPLAYS) >= 8 and len(RESETS) >= 4 and len(TRAJS) >= 4
+    # round 4: BASELINE config 1 at its stated length, and the reference's largest parametrisation with slip
+    names = {os.path.basename(p) for p in TRAJS + DIGESTS + REPLAYS + RESETS}
+    assert {"traj_5x4_s0_seed0_10k.npz", "traj_5x4_s0p2_seed0_10k.npz", "digest_11x7_s0p2.npz", "replay_11x7_s0p2.npz",
+            "reset_11x7_s0p2.npz", "digest_5x4_s0p2.npz"} <= names
 
 
 def test_philox_known_answers():
@@ -36,7 +44,7 @@ def test_philox_known_answers():
         ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
 
 
-@pytest.mark.parametrize("path", TABLES, ids=_ids(TABLES))
+@pytest.mark.parametrize("path", TABLES + DIGESTS, ids=_ids(TABLES + DIGESTS))
 def test_state_classification_and_isd(path):
     g = np.load(path)
     o = Oracle(int(g["width"]), int(g["height"]), float(g["slip"]))
@@ -77,6 +85,32 @@ def test_transition_table_row_for_row(path):
             o.transitions([xa, ya, xb, yb, p_], 0, 0)
 
 
+def test_digest_definition_on_a_table_that_is_also_stored_in_full():
+    """digest_5x4_s0p2.npz was written by the same reference run that table_5x4_s0p2.npz restates row by row: the digest of the
+    stored rows must be the stored digest (so a digest match on 11x7 means what a row-for-row match means here)."""
+    g = np.load(os.path.join(GOLDEN, "table_5x4_s0p2.npz")); d = np.load(os.path.join(GOLDEN, "digest_5x4_s0p2.npz"))
+    sha, per = table_digest(g["rows"], g["prob"])
+    assert sha == d["sha256"].item().decode() and len(g["rows"]) == int(d["n_rows"])
+    np.testing.assert_array_equal(per, d["tuple_digest"])
+
+
+@pytest.mark.parametrize("path", DIGESTS, ids=_ids(DIGESTS))
+def test_transition_table_digest(path):
+    """Tables too large to commit (11x7 with slip: 3.4 M rows): the oracle's complete table, dumped in the reference's own
+    iteration order, must hash to what the reference's table hashed to (gym_soccer/envs/soccer_simultaneous_env.py:167-293,
+    sizes of gym_soccer/tests/test_general.py:5-11).  A mismatch is localised by the per-tuple digests."""
+    d = np.load(path)
+    o = Oracle(int(d["width"]), int(d["height"]), float(d["slip"]))
+    rows, prob = o.dump_table()
+    assert len(rows) == int(d["n_rows"])
+    lens = np.diff(np.append(np.flatnonzero(rows[:, 7] == 0), len(rows)))
+    np.testing.assert_array_equal(np.bincount(lens, minlength=37), d["list_length_hist"])
+    sha, per = table_digest(rows, prob)
+    bad = np.flatnonzero(per != d["tuple_digest"])
+    assert bad.size == 0, "first differing state tuple (in order of appearance): %d" % bad[0]
+    assert sha == d["sha256"].item().decode()
+
+
 @pytest.mark.parametrize("path", REPLAYS, ids=_ids(REPLAYS))
 def test_replay_through_reference_step(path):
     g = np.load(path)
@@ -103,7 +137,7 @@ def test_replay_through_reference_step(path):
 def test_reset_vectors(path):
     g = np.load(path)
     n = len(g["u"])
-    o = Oracle(int(g["width"]), int(g["height"]), 0.0, n=n)
+    o = Oracle(int(g["width"]), int(g["height"]), float(g["slip"]) if "slip" in g.files else 0.0, n=n)
     obs = o.reset(u_reset=g["u"])
     st = g["state"]
     np.testing.assert_array_equal(obs, g["obs"])
