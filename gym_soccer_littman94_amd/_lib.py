@@ -59,6 +59,7 @@ class StagingView(C.Structure):
 
 
 STAGE_ACT_A, STAGE_ACT_B, STAGE_U_STEP, STAGE_U_RESET, STAGE_MASK = 1, 2, 4, 8, 16
+COMM_ID_BYTES = 128
 
 # name -> (restype, argtypes); every symbol include/soccer_hip.h declares
 PROTOTYPES = {
@@ -105,6 +106,15 @@ PROTOTYPES = {
     "soccer_tick": (C.c_uint64, [C.c_void_p]),
     "soccer_get_seed": (C.c_uint64, [C.c_void_p]),
     "soccer_set_tick": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "soccer_trajectory_returns": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64 * 3)]),
+    "soccer_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "soccer_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "soccer_comm_destroy": (C.c_int, [C.c_void_p]),
+    "soccer_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "soccer_comm_sum_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "soccer_comm_max_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "soccer_comm_barrier": (C.c_int, [C.c_void_p]),
     "soccer_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "soccer_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "soccer_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

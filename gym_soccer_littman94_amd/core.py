@@ -31,6 +31,22 @@ class DeviceArray:
         b._check(b.lib.soccer_memcpy_h2d(b.h, self.ptr, a.ctypes.data, self.nbytes))
         return self
 
+    def upload_rows(self, first_row, host):
+        """Copy `host` (rows of the same width) into rows first_row.. of a 2-D+ buffer."""
+        a = np.ascontiguousarray(host, dtype=self.dtype)
+        row_bytes = int(np.prod(self.shape[1:])) * self.dtype.itemsize
+        assert a.nbytes % row_bytes == 0 and int(first_row) * row_bytes + a.nbytes <= self.nbytes
+        b = self.batch
+        b._check(b.lib.soccer_memcpy_h2d(b.h, self.ptr + int(first_row) * row_bytes, a.ctypes.data, a.nbytes))
+        return self
+
+    def download_rows(self, first_row, n_rows):
+        row_bytes = int(np.prod(self.shape[1:])) * self.dtype.itemsize
+        out = np.empty((int(n_rows),) + self.shape[1:], self.dtype)
+        b = self.batch
+        b._check(b.lib.soccer_memcpy_d2h(b.h, out.ctypes.data, self.ptr + int(first_row) * row_bytes, out.nbytes))
+        return out
+
     def download(self, out=None):
         if out is None:
             out = np.empty(self.shape, self.dtype)
@@ -278,6 +294,41 @@ class SoccerBatch:
                         _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated), int(out_stride),
                         _ptr(return_sum), _ptr(episode_count), _ptr(mix_a), _ptr(mix_b))
         self._check(self.lib.batched_rollout(self.h, C.byref(a)))
+
+    def trajectory_returns(self, n_steps, reward, terminated, truncated, stride, last_return=None, episode_count=None, hist=True):
+        """soccer_trajectory_returns: one pass over [n_steps][n] result trajectories (device) -> per-lane return of the most recently
+        finished episode (int8[n]), per-lane finished-episode count (int32[n]) and, with hist=True (synchronises), the
+        (-1, 0, +1) histogram of every finished episode as a uint64[3] array."""
+        h3 = (C.c_uint64 * 3)() if hist else None
+        self._check(self.lib.soccer_trajectory_returns(self.h, int(n_steps), _ptr(reward), _ptr(terminated), _ptr(truncated), int(stride),
+                                                       _ptr(last_return), _ptr(episode_count), C.byref(h3) if hist else None))
+        return np.array(h3, dtype=np.uint64) if hist else None
+
+    # -- multi-GPU: RCCL over xGMI through the C ABI (one handle per process and GPU; see comm.py for the bring-up) -----
+    def comm_init(self, world, rank, unique_id):
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.soccer_comm_init(self.h, int(world), int(rank), buf))
+
+    def comm_destroy(self):
+        self._check(self.lib.soccer_comm_destroy(self.h))
+
+    def all_gather(self, send, recv, bytes_per_rank):
+        """recv[r * bytes_per_rank ...] = rank r's send[:bytes_per_rank] (device buffers; asynchronous on the handle's stream)."""
+        self._check(self.lib.soccer_comm_all_gather(self.h, _ptr(send), _ptr(recv), int(bytes_per_rank)))
+
+    def comm_sum(self, values):
+        a = np.ascontiguousarray(values, np.uint64).copy()
+        self._check(self.lib.soccer_comm_sum_u64(self.h, a.ctypes.data, int(a.size)))
+        return a
+
+    def comm_max(self, values):
+        a = np.ascontiguousarray(values, np.float64).copy()
+        self._check(self.lib.soccer_comm_max_f64(self.h, a.ctypes.data, int(a.size)))
+        return a
+
+    def comm_barrier(self):
+        self._check(self.lib.soccer_comm_barrier(self.h))
 
     @staticmethod
     def mixed_policy_thresholds(probs):

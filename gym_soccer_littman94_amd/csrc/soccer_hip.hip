@@ -5,6 +5,7 @@
 // on the handle's HIP stream.  There is no CPU execution path in this library: every batched_* call
 // is a kernel launch, and a missing/failed device is an error, not a fallback.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <atomic>
 #include <chrono>
@@ -76,6 +77,9 @@ struct soccer_handle {
     unsigned long long stamp_prev = 0;      // ... from this value (what the slot held when the replay was enqueued)
     unsigned long long swar_launch_lanes = kSwarLaunchLanes;   // lanes per step_kernel_swar / rollout_swar_kernel launch (SOCCER_SWAR_LAUNCH_LANES: tests of the split)
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
+    unsigned long long* d_traj_hist = nullptr;   // soccer_trajectory_returns: u64[3] the kernel adds into
+    void* comm = nullptr; int comm_world = 0, comm_rank = 0;   // soccer_comm_init: the RCCL communicator of this handle's device
+    unsigned long long* d_comm_scratch = nullptr;   // 64 B for the small reductions (barrier, histogram, clocks)
     PlanIO plan{};                          // cached planner lists (single-agent mode), see build_plan
     std::vector<void*> plan_bufs;
     bool plan_ready = false;
@@ -121,12 +125,16 @@ extern "C" int soccer_device_count(int* count) {
 
 extern "C" const char* soccer_last_error(const soccer_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
+static void comm_release(soccer_handle* h);
+
 static void free_handle(soccer_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
-    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_slip_lut, h->d_slip_step_lut};
+    comm_release(h);
+    void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_slip_lut, h->d_slip_step_lut,
+                    h->d_traj_hist, h->d_comm_scratch};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -1456,3 +1464,145 @@ extern "C" int soccer_graph_destroy(soccer_handle* h, soccer_graph* g) {
     delete g;
     return SOCCER_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// episode returns from [T][n] result trajectories (trajectory_returns_kernel)
+extern "C" int soccer_trajectory_returns(soccer_handle* h, int32_t n_steps, const int8_t* reward, const uint8_t* terminated,
+                                         const uint8_t* truncated, int64_t stride, int8_t* last_return,
+                                         int32_t* episode_count, uint64_t hist[3]) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_trajectory_returns during graph capture");
+    if (n_steps < 1 || !reward || !terminated || !truncated)
+        return fail(h, SOCCER_E_INVALID, "soccer_trajectory_returns: n_steps >= 1 and the reward / terminated / truncated trajectories are required");
+    if (stride < (int64_t)h->P.n) return fail(h, SOCCER_E_INVALID, "soccer_trajectory_returns: stride must be >= n_lanes");
+    if (!aligned(episode_count, 4)) return fail(h, SOCCER_E_INVALID, "soccer_trajectory_returns: episode_count must be 4-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->d_traj_hist) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_traj_hist), 64));
+    HIP_TRY(h, hipMemsetAsync(h->d_traj_hist, 0, 64, h->stream));
+    const unsigned long long n = h->P.n;
+    const bool vec = stride % 4 == 0 && aligned(reward, 4) && aligned(terminated, 4) && aligned(truncated, 4) &&
+                     aligned(last_return, 4) && aligned(episode_count, 16);
+    const unsigned long long n4 = vec ? (n & ~3ull) : 0ull;
+    TrajIO io{reward, terminated, truncated, (long long)stride, n_steps, n4, last_return, episode_count, h->d_traj_hist};
+    if (n4) hipLaunchKernelGGL(trajectory_returns_kernel<true>, dim3(grid_for(h, n4 >> 2)), dim3(kBlock), 0, h->stream, io);
+    if (n4 < n) {               // ragged tail, or everything when a stream is not dword-aligned: a lane per thread
+        TrajIO t = io;
+        t.reward += n4; t.terminated += n4; t.truncated += n4; t.n = n - n4;
+        t.last_return = off(last_return, n4); t.episode_count = off(episode_count, n4);
+        hipLaunchKernelGGL(trajectory_returns_kernel<false>, dim3(grid_for(h, t.n)), dim3(kBlock), 0, h->stream, t);
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (hist) {
+        unsigned long long out[3] = {0, 0, 0};
+        HIP_TRY(h, hipMemcpyAsync(out, h->d_traj_hist, sizeof out, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        hist[0] = out[0]; hist[1] = out[1]; hist[2] = out[2];
+    }
+    return SOCCER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL over xGMI: the job's only exchange (BASELINE configs[3]: gather of per-lane episode returns).
+// librccl is resolved at run time — a process that never calls soccer_comm_* never loads it — first among the symbols
+// already in the process (a host that brought its own copy), then as librccl.so.1 next to the HIP runtime.
+struct IdByValue { char internal[SOCCER_COMM_ID_BYTES]; };      // ncclUniqueId: passed BY VALUE to ncclCommInitRank (rccl.h:43, :220)
+namespace {
+struct Rccl {
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, IdByValue, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false; std::string why;
+};
+}  // namespace
+
+static Rccl& rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* lib = nullptr;
+        if (!dlsym(RTLD_DEFAULT, "ncclGetUniqueId")) {
+            for (const char* name : {"librccl.so.1", "librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+            if (!lib) { const char* e = dlerror(); R.why = std::string("librccl not found: ") + (e ? e : "?"); return; }
+        }
+        auto sym = [&](const char* n) -> void* { void* p = lib ? dlsym(lib, n) : dlsym(RTLD_DEFAULT, n); if (!p) R.why = std::string("librccl lacks ") + n; return p; };
+        R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
+        R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
+        R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+        R.AllGather = reinterpret_cast<decltype(R.AllGather)>(sym("ncclAllGather"));
+        R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(sym("ncclAllReduce"));
+        R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+        R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.AllGather && R.AllReduce && R.GetErrorString;
+    });
+    return R;
+}
+#define RCCL_TRY(h, expr)                                                                        \
+    do {                                                                                         \
+        const int r_ = (expr);                                                                   \
+        if (r_ != 0) return fail((h), SOCCER_E_HIP, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
+    } while (0)
+
+static void comm_release(soccer_handle* h) {
+    if (h && h->comm) { if (rccl().ok) (void)rccl().CommDestroy(h->comm); h->comm = nullptr; h->comm_world = 0; }
+}
+
+extern "C" int soccer_comm_unique_id(uint8_t id[SOCCER_COMM_ID_BYTES]) {
+    if (!id) return fail(nullptr, SOCCER_E_INVALID, "id is NULL");
+    if (!rccl().ok) return fail(nullptr, SOCCER_E_HIP, "%s", rccl().why.c_str());
+    static_assert(SOCCER_COMM_ID_BYTES == 128, "ncclUniqueId is 128 bytes (rccl.h: NCCL_UNIQUE_ID_BYTES)");
+    RCCL_TRY(nullptr, rccl().GetUniqueId(id));
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_comm_init(soccer_handle* h, int32_t world, int32_t rank, const uint8_t id[SOCCER_COMM_ID_BYTES]) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_comm_init during graph capture");
+    if (world < 1 || rank < 0 || rank >= world || !id) return fail(h, SOCCER_E_INVALID, "soccer_comm_init: need 0 <= rank < world and the unique id of rank 0");
+    if (h->comm) return fail(h, SOCCER_E_STATE, "soccer_comm_init: this handle already has a communicator");
+    if (!rccl().ok) return fail(h, SOCCER_E_HIP, "%s", rccl().why.c_str());
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->d_comm_scratch) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_comm_scratch), 64));
+    IdByValue v; std::memcpy(v.internal, id, sizeof v.internal);
+    RCCL_TRY(h, rccl().CommInitRank(&h->comm, world, v, rank));
+    h->comm_world = world; h->comm_rank = rank;
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_comm_destroy(soccer_handle* h) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    comm_release(h);
+    return SOCCER_OK;
+}
+
+extern "C" int soccer_comm_all_gather(soccer_handle* h, const void* send, void* recv, uint64_t bytes_per_rank) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (!h->comm) return fail(h, SOCCER_E_STATE, "soccer_comm_all_gather: no communicator (soccer_comm_init)");
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "soccer_comm_all_gather during graph capture");
+    if (!send || !recv) return fail(h, SOCCER_E_INVALID, "soccer_comm_all_gather: send/recv is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    RCCL_TRY(h, rccl().AllGather(send, recv, (size_t)bytes_per_rank, /*ncclInt8*/ 0, h->comm, h->stream));
+    return SOCCER_OK;
+}
+
+// small host-value reductions through the handle's 64-byte device scratch: up to 8 values, SUM of uint64 or MAX of float64.
+// Synchronises (the result is returned to the host) — which also makes it the job's barrier.
+static int comm_reduce_small(soccer_handle* h, void* values, int32_t count, bool f64_max, const char* what) {
+    if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
+    if (!h->comm) return fail(h, SOCCER_E_STATE, "%s: no communicator (soccer_comm_init)", what);
+    if (h->capturing) return fail(h, SOCCER_E_STATE, "%s during graph capture", what);
+    if (!values || count < 1 || count > 8) return fail(h, SOCCER_E_INVALID, "%s: 1..8 values", what);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_comm_scratch, values, 8 * (size_t)count, hipMemcpyHostToDevice, h->stream));
+    RCCL_TRY(h, rccl().AllReduce(h->d_comm_scratch, h->d_comm_scratch, (size_t)count, f64_max ? /*ncclFloat64*/ 8 : /*ncclUint64*/ 5,
+                                 f64_max ? /*ncclMax*/ 2 : /*ncclSum*/ 0, h->comm, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(values, h->d_comm_scratch, 8 * (size_t)count, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SOCCER_OK;
+}
+extern "C" int soccer_comm_sum_u64(soccer_handle* h, uint64_t* values, int32_t count) { return comm_reduce_small(h, values, count, false, "soccer_comm_sum_u64"); }
+extern "C" int soccer_comm_max_f64(soccer_handle* h, double* values, int32_t count) { return comm_reduce_small(h, values, count, true, "soccer_comm_max_f64"); }
+extern "C" int soccer_comm_barrier(soccer_handle* h) { uint64_t one = 1; return comm_reduce_small(h, &one, 1, false, "soccer_comm_barrier"); }

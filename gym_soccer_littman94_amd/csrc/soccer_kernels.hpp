@@ -2000,4 +2000,64 @@ __global__ __launch_bounds__(1024) void planner_kernel(const PlanIO IO) {
     if (tid == 0) { IO.counters[0] = outer; IO.counters[1] = sweeps; IO.counters[2] = capped; }
 }
 
+// =================================================================================================
+// episode returns from result trajectories (soccer_trajectory_returns)
+// =================================================================================================
+// What the caller of T batched_step calls (or of one batched_rollout) holds afterwards is [T][n] reward / terminated / truncated
+// streams; what BASELINE config 4 gathers over xGMI is ONE value per lane — player A's return of the lane's most recently
+// finished episode (= the reward of the step that ended it: only that step can carry one, :235-240) — plus the 3-bin histogram
+// of all finished episodes.  One pass over the three streams, 3 B per env-step read, 1 (+4) B per lane written: HBM-bound.
+// VEC: four lanes per thread by dword (streams 4-aligned, stride % 4 == 0); otherwise a lane per thread by byte.
+struct TrajIO {
+    const int8_t* reward; const uint8_t* terminated; const uint8_t* truncated;
+    long long stride; int32_t n_steps; unsigned long long n;
+    int8_t* last_return; int32_t* episode_count;       // nullable
+    unsigned long long* hist;                           // device u64[3]: return -1, 0, +1 (atomics)
+};
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void trajectory_returns_kernel(const TrajIO IO) {
+    uint32_t fin_t = 0u, nz_t = 0u, neg_t = 0u;
+    const unsigned long long units = VEC ? (IO.n >> 2) : IO.n;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; g < units;
+         g += (unsigned long long)gridDim.x * kBlock) {
+        if (VEC) {
+            const unsigned long long i0 = g << 2;
+            uint32_t last = 0u, c8 = 0u, cnt[4] = {0u, 0u, 0u, 0u};
+            for (int s = 0; s < IO.n_steps; ++s) {
+                const long long row = (long long)s * IO.stride;
+                const uint32_t r = *reinterpret_cast<const uint32_t*>(IO.reward + row + i0);
+                const uint32_t f = *reinterpret_cast<const uint32_t*>(IO.terminated + row + i0) |
+                                   *reinterpret_cast<const uint32_t*>(IO.truncated + row + i0);
+                const uint32_t nz = ((f | ((f & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;     // 0 / 1 per byte
+                const uint32_t m = nz * 255u, rm = r & m;
+                last = (last & ~m) | rm;
+                c8 += nz;
+                if ((s & 127) == 127) { for (int j = 0; j < 4; ++j) cnt[j] += (c8 >> (8 * j)) & 0xffu; c8 = 0u; }
+                fin_t += (uint32_t)__builtin_popcount(nz); nz_t += (uint32_t)__builtin_popcount(rm & 0x01010101u);
+                neg_t += (uint32_t)__builtin_popcount(rm & 0x80808080u);
+            }
+            for (int j = 0; j < 4; ++j) cnt[j] += (c8 >> (8 * j)) & 0xffu;
+            if (IO.last_return) *reinterpret_cast<uint32_t*>(IO.last_return + i0) = last;
+            if (IO.episode_count) *reinterpret_cast<int4*>(IO.episode_count + i0) = make_int4((int)cnt[0], (int)cnt[1], (int)cnt[2], (int)cnt[3]);
+        } else {
+            int8_t last = 0; uint32_t cnt = 0u;
+            for (int s = 0; s < IO.n_steps; ++s) {
+                const long long row = (long long)s * IO.stride;
+                const int8_t r = IO.reward[row + g];
+                if (IO.terminated[row + g] | IO.truncated[row + g]) {
+                    last = r; ++cnt; ++fin_t; nz_t += r != 0 ? 1u : 0u; neg_t += r < 0 ? 1u : 0u;
+                }
+            }
+            if (IO.last_return) IO.last_return[g] = last;
+            if (IO.episode_count) IO.episode_count[g] = (int32_t)cnt;
+        }
+    }
+    const uint32_t tot = wave_sum(fin_t), nzs = wave_sum(nz_t), neg = wave_sum(neg_t);
+    if ((threadIdx.x & 63u) == 0u && tot) {
+        if (neg) atomicAdd(IO.hist, (unsigned long long)neg);
+        if (tot - nzs) atomicAdd(IO.hist + 1, (unsigned long long)(tot - nzs));
+        if (nzs - neg) atomicAdd(IO.hist + 2, (unsigned long long)(nzs - neg));
+    }
+}
+
 }  // namespace soccer

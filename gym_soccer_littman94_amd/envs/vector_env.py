@@ -196,6 +196,8 @@ class VectorSoccerEnv:
         """Reset every lane (or the lanes selected by `mask`, e.g. the finished ones when auto-reset
         is off).  `seed` re-keys the per-lane Philox streams (np_random.seed in the reference, :411-412)."""
         b = self._batch
+        if self.strict and self.io == "device" and b.peek_misuse():     # what the steps before this reset raised (strict mode
+            self._raise_on_misuse()                                       # looks every 4th step only: nothing is lost here)
         if seed is not None:
             b.seed(seed)
         p = np.round(1.0 / b.n_isd, 2)
@@ -270,7 +272,8 @@ class VectorSoccerEnv:
         # table[b & 7] with 5..7 = NOOP (never an out-of-table access) and raise a sticky flag for any byte outside 0..4;
         # strict mode looks at the flags of the launches completed so far (a host-mapped word, no synchronisation; every
         # fourth step — this call is host-bound at 2^20 lanes, every microsecond of Python shows), so a bad action or a step
-        # on finished lanes surfaces as the reference's AssertionError a few steps late.
+        # on finished lanes surfaces as the reference's AssertionError up to 4 steps late; reset(), rollout(),
+        # episode_histogram() and close() look too, so every misuse is reported eventually.
         self._steps = steps = self._steps + 1
         if self.strict and not (steps & 3) and b.peek_misuse():
             self._raise_on_misuse()
@@ -285,6 +288,122 @@ class VectorSoccerEnv:
                 lz.invalidate()
             del self._stale[:]
         return self._ret_obs, self._ret_rew, self._ret_term, self._ret_trunc, self._ret_infos
+
+    # ---------------------------------------------------------------------------------------------
+    def rollout(self, n_steps, actions=None, sample_actions=False, mixed_policies=None):
+        """T = `n_steps` fused steps — by definition EXACTLY what T successive `step()` calls return, stacked over T (same
+        ticks, same auto-reset convention: soccer_simultaneous_env.py:397-408 per step) — in one or two launches instead of T:
+        `batched_rollout` keeps the state in registers for the first T - 1 steps and the last step is a full `batched_step`, so
+        that the last step's `infos` are there as after `step()`.
+
+        actions  dict like step()'s, every value [T, num_envs] (device io: contiguous torch.int8 CUDA tensors; numpy io: integer
+                 arrays, checked to be 0..4 on the host).  Single-agent mode: the learner's key only.
+        sample_actions=True (actions None)  both players act uniformly at random, drawn in the kernel from the lanes' purpose-1
+                 Philox words (include/soccer_hip.h); `mixed_policies` = {agent: [nS, 5] probabilities} samples that agent's
+                 action from its row of the current observation instead (BASELINE config 5).  All T steps are fused and `infos`
+                 then holds `_final_observation` only.
+
+        Returns (observations, rewards, terminated, truncated, infos): dicts per returned agent of [T, num_envs] arrays —
+        uint16 observations, float32 rewards (device io: cast from the kernel's int8 trajectory on first access; the int8
+        trajectory of player A's reward is infos["reward_int8"]), bool flags — and the LAST step's infos.  The arrays are
+        buffers the env owns, one set per T, overwritten by the next rollout of the same length."""
+        assert not self._needs_reset, "Please reset the environment before taking a step"
+        T, n, b = int(n_steps), self.num_envs, self._batch
+        assert T >= 1, "n_steps must be >= 1"
+        ags = self.return_agent
+        if sample_actions:
+            assert actions is None and self.multiagent, "sample_actions: no action streams, both players are sampled"
+            a = bb = None
+        else:
+            assert mixed_policies is None, "mixed_policies needs sample_actions=True"
+            a, bb = self._check_actions(actions)
+        if self.io == "device":
+            return self._rollout_device(T, a, bb, sample_actions, mixed_policies)
+        # ---- numpy io: host arrays in, host arrays out; same kernels, one upload and one download -------------------
+        dev = {}
+        for key, x in (("a", a), ("b", bb)):
+            if x is None:
+                continue
+            x = np.asarray(x)
+            assert x.shape == (T, n), "one action per step, environment and agent: [n_steps, num_envs]"
+            assert ((x >= 0) & (x < self.nA)).all(), "actions must be in 0..4"
+            dev[key] = b.alloc((T, n), np.int8).upload(x.astype(np.int8, copy=False))
+        obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8)
+        term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
+        fin = b.alloc(n, np.uint16); code = b.alloc(n, np.uint8)
+        mix = self._mix_tables(mixed_policies, lambda t: b.alloc(t.shape, np.uint16).upload(t)) if sample_actions else {}
+        self._rollout_launch(T, dev.get("a"), dev.get("b"), sample_actions, mix, obs, rew, term, trunc, fin, code, None,
+                             lambda arr, k: None if arr is None else arr.row(k))
+        O, R = obs.download(), rew.download().astype(np.float32)
+        TE, TR = term.download().view(np.bool_), trunc.download().view(np.bool_)
+        infos = {"_final_observation": TE[-1] | TR[-1], "reward_int8": R.astype(np.int8)}
+        if not sample_actions:
+            c = code.download(); f = fin.download()
+            lazy = _LazyInfo(lambda: self._p_rounded[c])
+            infos.update({ag: lazy for ag in ags}); infos["final_observation"] = {ag: f for ag in ags}
+        for x in list(dev.values()) + [obs, rew, term, trunc, fin, code] + list(mix.values()):
+            x.free()
+        if self.strict:
+            self._raise_on_misuse()
+        return ({ag: O for ag in ags}, self._rewards(R), {ag: TE for ag in ags}, {ag: TR for ag in ags}, infos)
+
+    def _mix_tables(self, mixed_policies, put):
+        out = {}
+        for ag, probs in (mixed_policies or {}).items():
+            assert ag in AGENTS, "mixed_policies keys are 'player_a' / 'player_b'"
+            out[ag] = put(SoccerBatch.mixed_policy_thresholds(probs))
+        return out
+
+    def _rollout_launch(self, T, a, bb, sample, mix, obs, rew, term, trunc, fin, code, finished, row):
+        """the launches of one rollout; `row(buffer, k)` = device address of row k of a [T, n] buffer"""
+        b, n = self._batch, self.num_envs
+        if sample:
+            b.rollout(T, sample_actions=True, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
+                      mix_a=mix.get("player_a"), mix_b=mix.get("player_b"))
+            return
+        if T > 1:
+            b.rollout(T - 1, a, bb, act_stride=n, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n)
+        k = T - 1
+        b.step(row(a, k), row(bb, k), obs=row(obs, k), reward=row(rew, k), terminated=row(term, k), truncated=row(trunc, k),
+               prob_code=code, final_obs=fin, finished=finished)
+
+    def _rollout_device(self, T, a, bb, sample, mixed_policies):
+        t, n, d, b = self._torch, self.num_envs, self._dev, self._batch
+        for x in (a, bb):
+            assert x is None or (x.dtype is t.int8 and x.is_cuda and x.shape == (T, n) and x.is_contiguous()), \
+                "device io expects contiguous torch.int8 CUDA tensors of shape [n_steps, num_envs]"
+        if self.strict and b.peek_misuse():           # (like step(): what the launches completed so far have raised)
+            self._raise_on_misuse()
+        bufs = self._roll_bufs.get(T) if hasattr(self, "_roll_bufs") else None
+        if bufs is None:
+            if not hasattr(self, "_roll_bufs"):
+                self._roll_bufs = {}
+                u16 = getattr(t, "uint16", t.int16)
+                self._r_fin = t.zeros(n, dtype=u16, device=d); self._r_code = t.zeros(n, dtype=t.uint8, device=d)
+                self._r_finished = t.zeros(n, dtype=t.uint8, device=d)
+            u16 = getattr(t, "uint16", t.int16)
+            bufs = (t.empty((T, n), dtype=u16, device=d), t.empty((T, n), dtype=t.int8, device=d),
+                    t.empty((T, n), dtype=t.uint8, device=d), t.empty((T, n), dtype=t.uint8, device=d))
+            self._roll_bufs = {T: bufs}               # one set: a new length replaces the old buffers
+        obs, rew, term, trunc = bufs
+        mix = self._mix_tables(mixed_policies, lambda tab: t.from_numpy(tab.view(np.int16)).to(d)) if sample else {}
+        self._rollout_launch(T, a, bb, sample, mix, obs, rew, term, trunc, self._r_fin, self._r_code, self._r_finished,
+                             lambda x, k: None if x is None else x[k])
+        ags = self.return_agent
+        term_b, trunc_b = term.view(t.bool), trunc.view(t.bool)
+        thunks = {}
+        if 'player_a' in ags: thunks['player_a'] = lambda: rew.to(t.float32)
+        if 'player_b' in ags: thunks['player_b'] = lambda: 0.0 - rew.to(t.float32)          # :400-402, :243-244
+        infos = {"reward_int8": rew}
+        if sample:
+            infos = _Lazy({"_final_observation": lambda: term_b[-1] | trunc_b[-1]}, infos)
+        else:
+            code = self._r_code
+            lazy = _LazyInfo(lambda: self._prob[code.long()])
+            infos.update({ag: lazy for ag in ags})
+            infos["final_observation"] = {ag: self._r_fin for ag in ags}
+            infos["_final_observation"] = self._r_finished.view(t.bool)
+        return ({ag: obs for ag in ags}, _Lazy(thunks), {ag: term_b for ag in ags}, {ag: trunc_b for ag in ags}, infos)
 
     @property
     def reward_int8(self):
@@ -321,13 +440,31 @@ class VectorSoccerEnv:
         self._needs_reset = False
 
     def episode_histogram(self):
-        """Counts of finished episodes by player A's return (-1, 0, +1); not collected with info=False."""
+        """Counts of finished episodes by player A's return (-1, 0, +1); not collected with info=False.  Synchronises, so
+        strict mode reports any misuse the steps so far have raised."""
         assert self.info, "the episode histogram is not collected with info=False"
-        return self._batch.stats()[0]
+        hist, flags = self._batch.stats()
+        if self.strict and flags:
+            self._raise_on_misuse()
+        return hist
 
     @property
     def batch(self):
         return self._batch
 
     def close(self):
+        """Frees the handle.  strict mode: a misuse raised by the last steps (device io reports up to 4 steps late, see step())
+        is reported here at the latest — after the handle is gone, as the reference's assert would have been (:376, :393)."""
+        flags = 0
+        if self.strict and self._batch.h:
+            try:
+                flags = self._batch.misuse()         # synchronises: everything enqueued has run
+            except Exception:
+                flags = 0
         self._batch.close()
+        if flags & SoccerBatch.MISUSE_ACTION:
+            raise AssertionError("actions must be in 0..4 (an action byte outside that range reached the device; "
+                                 "it was executed as a move inside the pitch)")
+        if flags:
+            raise AssertionError("Please reset the environment before taking a step "
+                                 "(some lanes had terminated or truncated; they were left untouched)")

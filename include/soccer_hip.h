@@ -340,6 +340,37 @@ uint64_t soccer_tick(const soccer_handle* h);
 uint64_t soccer_get_seed(const soccer_handle* h);
 int soccer_set_tick(soccer_handle* h, uint64_t tick);
 
+/* Episode returns from [n_steps][n_lanes] result trajectories — what n_steps batched_step calls or one batched_rollout
+ * wrote (DEVICE pointers, row stride `stride` elements): one pass over the three streams.
+ *   last_return[i]   (nullable, device int8[n])  player A's return of lane i's most recently finished episode = the reward
+ *                    of the last step at which terminated | truncated was set (:235-240, :400-404); 0 if none finished
+ *   episode_count[i] (nullable, device int32[n]) episodes lane i finished during the n_steps steps
+ *   hist             (nullable, HOST uint64[3])  all finished episodes by A's return -1, 0, +1; when given the call synchronises
+ * This is the per-lane value BASELINE configs[3] gathers across GPUs (soccer_comm_all_gather). */
+int soccer_trajectory_returns(soccer_handle* h, int32_t n_steps, const int8_t* reward, const uint8_t* terminated,
+                              const uint8_t* truncated, int64_t stride, int8_t* last_return,
+                              int32_t* episode_count, uint64_t hist[3]);
+
+/* ---- multi-GPU: RCCL over xGMI (the reference has no counterpart) ------------------------------------
+ * One process and one handle per GPU; lanes never interact, so stepping needs NO collective.  The only exchange is after a
+ * run: an all-gather of per-lane episode returns into global lane order and small reductions (the 3-bin histogram, clocks).
+ * librccl is resolved at run time (dlopen), so a single-GPU process never loads it.
+ *   soccer_comm_unique_id   rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to every rank by any host channel
+ *                           (gym_soccer_littman94_amd/comm.py: a file next to the launcher, or the caller's own)
+ *   soccer_comm_init        ncclCommInitRank on the handle's device; collective over all `world` ranks
+ *   soccer_comm_all_gather  recv[r * bytes_per_rank ...] = rank r's send[0 .. bytes_per_rank) (DEVICE pointers; enqueued on
+ *                           the handle's stream, asynchronous): equal contiguous shards land in global lane order
+ *   soccer_comm_sum_u64 / soccer_comm_max_f64 / soccer_comm_barrier   1..8 HOST values reduced over the ranks in place;
+ *                           these synchronise the stream (the barrier is a one-element sum) */
+#define SOCCER_COMM_ID_BYTES 128
+int soccer_comm_unique_id(uint8_t id[SOCCER_COMM_ID_BYTES]);
+int soccer_comm_init(soccer_handle* h, int32_t world, int32_t rank, const uint8_t id[SOCCER_COMM_ID_BYTES]);
+int soccer_comm_destroy(soccer_handle* h);
+int soccer_comm_all_gather(soccer_handle* h, const void* send, void* recv, uint64_t bytes_per_rank);
+int soccer_comm_sum_u64(soccer_handle* h, uint64_t* values, int32_t count);
+int soccer_comm_max_f64(soccer_handle* h, double* values, int32_t count);
+int soccer_comm_barrier(soccer_handle* h);
+
 /* ---- device memory + timing helpers (so a host without torch can drive the library) ------ */
 int soccer_malloc(soccer_handle* h, size_t bytes, void** dptr);
 int soccer_free(soccer_handle* h, void* dptr);

@@ -1,8 +1,10 @@
 """bench.py must be able to bring up its own ranks: the driver starts it as `python bench.py --gpus N`.
 
 CPU-only rehearsal of the launcher (no GPU work, no measurement): the parent spawns N fresh children with
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set before anything could touch a GPU, the ranks rendezvous over
-gloo on 127.0.0.1, rank 0 prints the single JSON line, and a failing rank makes the whole run fail."""
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set before anything could touch a GPU, the ranks rendezvous through the
+host-file communicator (gym_soccer_littman94_amd/comm.py), rank 0 prints the single JSON line, and a failing rank makes
+the whole run fail.  Also: the shape of the timed region (no collective between the clock's start and stop) and the
+torch-freeness of the rank processes."""
 import json
 import os
 import subprocess
@@ -80,3 +82,87 @@ def test_parent_does_not_import_torch_or_load_hip():
     assert "import torch" not in body and "_lib" not in body and "SoccerBatch" not in body
     head = src[:src.index("def cpu_baseline")]
     assert "import torch" not in head and "gym_soccer_littman94_amd" not in head
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def test_no_collective_inside_the_timed_region():
+    """the N > 1 region used to close on a dist.barrier().  The region is ONE function used at every N; with spies
+    for everything it calls, the job barrier must come before the clock starts and nothing but this rank's own launch and
+    device synchronisation may happen between t0 and the clock's stop."""
+    bench = _load_bench()
+    log = []
+    clock = iter(range(100))
+
+    def now():
+        log.append("clock"); return float(next(clock))
+    t0, t1, t2 = bench.timed_region(lambda: log.append("job_barrier"), lambda: log.append("device_sync"),
+                                    lambda: log.append("launch"), now)
+    assert log == ["job_barrier", "device_sync", "clock", "launch", "clock", "device_sync", "clock"]
+    assert (t0, t1, t2) == (0.0, 1.0, 2.0)
+    log.clear()
+    bench.timed_region(None, lambda: log.append("device_sync"), lambda: log.append("launch"), now)      # N = 1: the same region
+    assert log == ["device_sync", "clock", "launch", "clock", "device_sync", "clock"]
+    # and main() hands it the communicator's barrier and nothing else: no comm call appears between the call and the clocks' use
+    src = open(BENCH).read()
+    call = src.index("timed_region(comm.barrier if comm else None, device_sync, launch, time.perf_counter)")
+    after = src[call:src.index("per_rank = None", call)]
+    assert "comm." not in after.split("\n", 1)[1], "a communicator call between the timed region and the per-rank clocks"
+    launch_body = src[src.index("def launch():"):call]
+    assert "comm" not in launch_body and "barrier" not in launch_body
+
+
+def test_rank_processes_are_torch_free():
+    """torch (and with it PyTorch's bundled, older HIP runtime) is imported in ONE function: the vector-env child leg."""
+    src = open(BENCH).read()
+    leg = src[src.index("def vector_env_leg"):src.index("def run_vector_env_child")]
+    rest = src.replace(leg, "")
+    assert "import torch" in leg and "import torch" not in rest and "init_process_group" not in rest and "dist." not in rest
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import gym_soccer_littman94_amd, gym_soccer_littman94_amd.comm; "
+            "assert 'torch' not in sys.modules" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_gpu_local_cpus_never_raises_and_stays_inside_the_affinity_mask():
+    bench = _load_bench()
+    cpus, note = bench.gpu_local_cpus(0, 1)
+    assert isinstance(note, str) and (cpus is None or set(cpus) <= set(os.sched_getaffinity(0)))
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def _host_comm_worker(rank, world, directory, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from gym_soccer_littman94_amd.comm import HostComm
+    c = HostComm(rank, world, timeout=30.0, directory=directory)
+    c.barrier()
+    s = c.sum_u64([rank + 1, 10 * (rank + 1), 7])
+    m = c.max_f64([float(rank), -float(rank)])
+    g = c.gather_f64([100.0 + rank, 0.5 * rank])
+    for _ in range(20):                       # many exchanges: the files of finished exchanges are cleaned up as it goes
+        c.barrier()
+    left = len(os.listdir(directory))
+    c.close()
+    q.put((rank, s.tolist(), m.tolist(), g.tolist(), left))
+
+
+def test_host_file_communicator_three_ranks(tmp_path):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_host_comm_worker, args=(r, world, str(tmp_path / "rdv"), q)) for r in range(world)]
+    os.makedirs(str(tmp_path / "rdv"))
+    for p in ps: p.start()
+    got = sorted(q.get(timeout=60) for _ in range(world))
+    for p in ps: p.join(30)
+    for rank, s, m, g, left in got:
+        assert s == [6, 60, 21] and m == [2.0, 0.0]
+        assert g == [[100.0, 0.0], [101.0, 0.5], [102.0, 1.0]]
+        assert left <= 2 * world
