@@ -167,9 +167,16 @@ class SoccerBatch:
         """Everything that determines the handle's future: the state streams, the Philox seed and the tick."""
         ck = self.get_state()
         ck["seed"] = int(self.lib.soccer_get_seed(self.h)); ck["tick"] = self.tick
+        ck["rng_abi"] = int(self.lib.soccer_abi_version())      # the bits -> uniform convention the (seed, tick) pair is meant for
         return ck
 
     def restore(self, ck):
+        """Raises AssertionError for a checkpoint taken under another RNG convention (include/soccer_hip.h, SOCCER_ABI_VERSION:
+        ABI 3 changed the bits -> uniform mapping, so the same (seed, tick) would continue on a different random stream); a
+        checkpoint without the field predates ABI 3's field and is refused for the same reason."""
+        abi = int(self.lib.soccer_abi_version())
+        assert ck.get("rng_abi") == abi, \
+            "checkpoint was taken under RNG ABI %r, this library is ABI %d: resuming would silently change the random stream" % (ck.get("rng_abi"), abi)
         self.set_state(ck["row_a"], ck["col_a"], ck["row_b"], ck["col_b"], ck["poss"], t=ck["t"],
                        needs_reset=ck["needs_reset"])
         self.seed(ck["seed"])

@@ -64,6 +64,7 @@ struct soccer_handle {
     int capture_calls = 0;
     int capture_start_slot = 0;
     int n_cu = 256;
+    size_t lds_limit = 64 * 1024;           // hipDeviceProp_t::sharedMemPerBlockOptin: what a workgroup may be given (160 KB on gfx950)
     uint4* d_sub = nullptr;                 // integer slip thresholds (KernelParams::sub)
     uint4* rec_host = nullptr; uint4* rec_dev = nullptr; uint32_t rec_seq = 0;   // soccer_step_scalar's mapped result record
     // byte-parallel step (soccer_swar.hpp)
@@ -73,6 +74,7 @@ struct soccer_handle {
     uint32_t* d_slip_step_lut = nullptr;    // SlipTables::lut_step + T: the single step's table (when lut_step_ok)
     size_t hist_slots = kHistSlots;         // per-wave histogram slots (a power of two; see soccer_create)
     bool timer_stamped = false; int wall_clock_khz = 100000;   // captured timers: see stamp_kernel
+    bool capture_stamped = false;           // THIS capture recorded soccer_timer_start / _mark (what soccer_graph::stamped is copied from)
     bool stamp_poll = false;                // soccer_timer_read may watch the closing stamp of the last soccer_graph_launch change ...
     unsigned long long stamp_prev = 0;      // ... from this value (what the slot held when the replay was enqueued)
     unsigned long long swar_launch_lanes = kSwarLaunchLanes;   // lanes per step_kernel_swar / rollout_swar_kernel launch (SOCCER_SWAR_LAUNCH_LANES: tests of the split)
@@ -325,6 +327,8 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device) == hipSuccess && khz > 0) h->wall_clock_khz = khz; }
     h->grid_cap = prop.multiProcessorCount * 8;
     h->n_cu = prop.multiProcessorCount;
+    if (prop.sharedMemPerBlockOptin > 0) h->lds_limit = prop.sharedMemPerBlockOptin;
+    else if (prop.sharedMemPerBlock > 0) h->lds_limit = prop.sharedMemPerBlock;
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     *out = h;
@@ -599,12 +603,17 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             RS.tab_off = (uint32_t)(smem / sizeof(uint32_t));
             const bool fixed = P.policy_a || P.policy_b;
             // both sides sampled from mixed-policy tables whose 16-byte rows fit LDS: the shape of config 5
+            // what the tables may take: the device's per-workgroup LDS limit (64 KB on CDNA3, 160 KB on gfx950 — never a literal)
+            // minus the action staging area that is added below and the static bucket table of sm == 2
+            const size_t staging = io.sample_actions ? 0 : 16 * kBlock * sizeof(uint32_t) + 16;
+            const size_t lds_cap = h->lds_limit > staging + (sm == 2 ? kSlipLutWords * sizeof(uint32_t) : 0)
+                                 ? h->lds_limit - staging - (sm == 2 ? kSlipLutWords * sizeof(uint32_t) : 0) : 0;
             const bool both_mix = dyn && !fixed && io.sample_actions && io.mix_a && io.mix_b &&
-                                  smem + (size_t)R0.nS * sizeof(uint4) <= 64 * 1024;
+                                  smem + (size_t)R0.nS * sizeof(uint4) <= lds_cap;
             if (both_mix) { RS.lds_tables = 1; smem += (size_t)R0.nS * sizeof(uint4); }
             else if (dyn && (io.mix_a || io.mix_b || fixed)) {
                 const size_t need = smem + 2 * (size_t)R0.nS * sizeof(uint2) + 2 * (((size_t)R0.nS + 15) & ~size_t(15));
-                if (need <= 64 * 1024) { RS.lds_tables = 1; smem = need; }
+                if (need <= lds_cap) { RS.lds_tables = 1; smem = need; }     // else: the tables stay in global memory
             }
             if (!io.sample_actions) {        // action streams are staged through LDS: 16 dwords per thread
                 smem = (smem + 15) & ~size_t(15);
@@ -627,7 +636,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             uint64_t blocks = (groups + kBlock - 1) / kBlock;
             if (blocks > (uint64_t)h->grid_cap) blocks = h->grid_cap;
             const dim3 g((unsigned)blocks), bl(kBlock);
-#define LAUNCH_G(DV, SV, GV) do { if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV, GV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+#define LAUNCH_G(DV, SV, GV) do { if (smem > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV, GV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
                                   hipLaunchKernelGGL((rollout_swar_kernel<DV, SV, GV>), g, bl, smem, h->stream, RS, io); } while (0)
 #define LAUNCH_S(DV, SV) do { if (h->swar_c.small) LAUNCH_G(DV, SV, 1); else LAUNCH_G(DV, SV, 0); } while (0)
             // the action source as a compile-time shape (rollout_swar_group): streams / sampled uniformly / both sides from
@@ -1326,7 +1335,7 @@ extern "C" int soccer_timer_start(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->timer_stamped = h->capturing;
-    if (h->capturing) return soccer_stamp(h, 0);
+    if (h->capturing) { h->capture_stamped = true; return soccer_stamp(h, 0); }
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     return SOCCER_OK;
 }
@@ -1334,7 +1343,7 @@ extern "C" int soccer_timer_mark(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (h->capturing) {
-        if (!h->timer_stamped) return fail(h, SOCCER_E_STATE, "soccer_timer_mark in a capture needs soccer_timer_start in the same capture");
+        if (!h->capture_stamped) return fail(h, SOCCER_E_STATE, "soccer_timer_mark in a capture needs soccer_timer_start in the same capture");
         return soccer_stamp(h, 1);
     }
     h->timer_stamped = false;
@@ -1398,12 +1407,16 @@ extern "C" int soccer_timer_stop(soccer_handle* h, float* elapsed_ms) {
 }
 
 // ------------------------------------------------------------------------------------------------
+__global__ void move_tick_kernel(unsigned long long* dst, const unsigned long long* src) {
+    if (threadIdx.x == 0) *dst = *src;
+}
+
 extern "C" int soccer_graph_begin(soccer_handle* h) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (h->capturing) return fail(h, SOCCER_E_STATE, "graph capture already in progress");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->capturing = true; h->capture_ticks = 0; h->capture_calls = 0;
+    h->capturing = true; h->capture_ticks = 0; h->capture_calls = 0; h->capture_stamped = false;
     h->capture_start_slot = h->tick_slot;
 
     return SOCCER_OK;
@@ -1412,18 +1425,18 @@ extern "C" int soccer_graph_begin(soccer_handle* h) {
 extern "C" int soccer_graph_end(soccer_handle* h, soccer_graph** out) {
     if (!h || !out) return fail(h, SOCCER_E_INVALID, "handle/out is NULL");
     if (!h->capturing) return fail(h, SOCCER_E_STATE, "no graph capture in progress");
+    if (h->capture_calls % 2 != 0) {
+        // An odd number of launches leaves the tick in the other slot, and the nodes' slot pointers are baked in: one more node
+        // (a one-thread kernel, ~1.5 us per replay; an even count needs none) moves it back to where a replay starts reading.
+        hipLaunchKernelGGL(move_tick_kernel, dim3(1), dim3(64), 0, h->stream,
+                           h->d_tick + (h->capture_start_slot ? 16 : 0), h->d_tick + (h->tick_slot ? 16 : 0));
+        h->tick_slot = h->capture_start_slot;
+    }
     h->capturing = false;
     hipGraph_t graph = nullptr;
     HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
-    if (h->capture_calls % 2 != 0) {
-        // an odd count would leave the tick in the other slot after a replay
-        h->tick_slot ^= 1;
-        (void)hipGraphDestroy(graph);
-        return fail(h, SOCCER_E_INVALID, "a captured sequence must contain an even number of batched_* calls (got %d)",
-                    h->capture_calls);
-    }
     soccer_graph* g = new soccer_graph();
-    g->graph = graph; g->ticks = h->capture_ticks; g->start_slot = h->capture_start_slot; g->stamped = h->timer_stamped;
+    g->graph = graph; g->ticks = h->capture_ticks; g->start_slot = h->capture_start_slot; g->stamped = h->capture_stamped;
     hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(graph); delete g;
@@ -1449,7 +1462,11 @@ extern "C" int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t re
     }
     // one replay: remember what the closing stamp holds, so that soccer_timer_read can watch it change (several replays
     // would each write it)
-    h->stamp_poll = replays == 1 && g->stamped;
+    // (only with the stream idle: a replay still in flight would write the slot AFTER it was sampled, and soccer_timer_read would
+    // return on that earlier replay's stamp; otherwise — and for graphs without timer nodes — soccer_timer_read waits for the stream)
+    h->stamp_poll = replays == 1 && g->stamped && hipStreamQuery(h->stream) == hipSuccess;
+    (void)hipGetLastError();
+    h->timer_stamped = g->stamped;          // soccer_timer_read after this launch: the graph's stamps, or the eager events
     if (h->stamp_poll) h->stamp_prev = stamp_host(h)[kStampStride];
     for (int32_t r = 0; r < replays; ++r) HIP_TRY(h, hipGraphLaunch(g->exec, h->stream));
     h->tick += g->ticks * (uint64_t)(replays > 0 ? replays : 0);

@@ -398,8 +398,9 @@ int soccer_stamps_clear(soccer_handle* h, int32_t first, int32_t count);
 int soccer_stamps_read(soccer_handle* h, int32_t first, int32_t count, uint64_t* ticks, int32_t* khz);
 
 /* ---- hipGraph capture of a sequence of batched_* calls ------------------------------------ */
-/* Calls between begin and end are recorded instead of executed.  The number of recorded
- * batched_* calls must be even (the tick lives in device memory in two alternating slots). */
+/* Calls between begin and end are recorded instead of executed.  Any number of batched_* calls may be recorded (the tick
+ * lives in device memory in two alternating slots so that a replay advances it; a sequence with an ODD number of calls
+ * gets one extra one-thread node that moves it back to the slot a replay starts from, ~1.5 us per replay). */
 int soccer_graph_begin(soccer_handle* h);
 int soccer_graph_end(soccer_handle* h, soccer_graph** out);
 int soccer_graph_launch(soccer_handle* h, soccer_graph* g, int32_t replays);

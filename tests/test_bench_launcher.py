@@ -110,10 +110,11 @@ def test_no_collective_inside_the_timed_region():
     assert log == ["device_sync", "clock", "launch", "clock", "device_sync", "clock"]
     # and main() hands it the communicator's barrier and nothing else: no comm call appears between the call and the clocks' use
     src = open(BENCH).read()
-    call = src.index("timed_region(comm.barrier if comm else None, device_sync, launch, time.perf_counter)")
-    after = src[call:src.index("per_rank = None", call)]
-    assert "comm." not in after.split("\n", 1)[1], "a communicator call between the timed region and the per-rank clocks"
-    launch_body = src[src.index("def launch():"):call]
+    body = src[src.index("def measure(job_barrier):"):src.index("per_rank = None")]
+    assert body.count("timed_region(") == 1 and "timed_region(job_barrier, device_sync, launch, time.perf_counter)" in body
+    inside = body[:body.index("# A rehearsal with more ranks than GPUs")]
+    assert "comm" not in inside, "a communicator call inside measure(): between the clock's start and the per-rank clocks"
+    launch_body = src[src.index("def launch():"):src.index("def measure(job_barrier):")]
     assert "comm" not in launch_body and "barrier" not in launch_body
 
 

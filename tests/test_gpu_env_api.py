@@ -509,6 +509,10 @@ def test_checkpoint_resume_reproduces_the_future():
     ck = v.checkpoint()
     fut = [v.step({'player_a': acts[k, 0], 'player_b': acts[k, 1]}) for k in range(40, 90)]
     w = VectorSoccerEnv(n, slip_prob=0.2, seed=123)           # a different env, different seed
+    # a checkpoint of another RNG convention (or of unknown convention) is refused: same (seed, tick), different random stream
+    for bad in (dict(ck, rng_abi=2), {k: x for k, x in ck.items() if k != "rng_abi"}):
+        with pytest.raises(AssertionError, match="RNG ABI"):
+            w.restore(bad)
     w.restore(ck)
     for k, ref in zip(range(40, 90), fut):
         got = w.step({'player_a': acts[k, 0], 'player_b': acts[k, 1]})

@@ -595,7 +595,26 @@ def test_clock_stamps_and_the_captured_timer():
     with pytest.raises(AssertionError):
         b.stamp(256)
     assert b.tick == 1 + K * 5          # the reset, K eager steps, three replays of K, K eager steps (the capture itself consumes none)
-    b.graph_destroy(g); b.close()
+    # a graph captured AFTER a stamped one has no timer nodes of its own: it is not "stamped", and the eager timer around its
+    # replay is the HIP-event one (the sticky handle flag used to mark it, and timer_read then polled a slot nobody wrote)
+    b.graph_begin()
+    for k in range(K):
+        b.step_plain(A, B, obs, rew, te, tr)
+    g2 = b.graph_end()
+    b.timer_start(); b.graph_launch(g2, 1); ms2 = b.timer_stop()
+    assert 0.2 * ms < ms2 < 20 * ms
+    # two replays of the stamped graph with no synchronisation in between: timer_read waits for the stream instead of trusting
+    # a closing stamp sampled while the first replay was still in flight, and returns the LAST replay's duration
+    b.graph_launch(g, 1); b.graph_launch(g, 1); ms3 = b.timer_read()
+    s01, _ = b.stamps(0, 2)
+    assert 0 < ms3 < 20 * ms and abs(ms3 - (int(s01[1]) - int(s01[0])) / khz) < 1e-6
+    # a capture that marks without starting is refused even though an EARLIER capture had a timer
+    b.graph_begin()
+    with pytest.raises(RuntimeError, match="needs soccer_timer_start"):
+        b.timer_mark()
+    b.step_plain(A, B, obs, rew, te, tr); b.step_plain(A, B, obs, rew, te, tr)
+    g3 = b.graph_end()
+    b.graph_destroy(g); b.graph_destroy(g2); b.graph_destroy(g3); b.close()
 
 
 @pytest.mark.parametrize("slip", [0.0, 0.2])
