@@ -441,7 +441,9 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
     const bool shared = ((P.lane_offset + P.first) & 3ull) == 0ull;
     const bool policy_only = explicit_u && !io.u_step && !io.u_reset;       // fixed-policy handle, Philox draws
     const bool swar_fit = vec && shared && h->swar_ok && (!h->slip || h->slip_swar_ok) && aligned(io.last_return, 4);
-    if ((policy_only || !explicit_u) && swar_fit) {
+    // caller-supplied uniforms at slip_prob == 0: floor(4u) is the reference's decision for any double (step_kernel_swar, EXPL)
+    const bool expl = explicit_u && !policy_only && !h->slip && aligned(io.u_step, 16) && aligned(io.u_reset, 16);
+    if ((policy_only || !explicit_u || expl) && swar_fit) {
         // the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
         // which outputs the launch needs decides the instantiation: 0 the four result streams, 1 + the gym floats /
         // finished / last_return, 2 + final_obs / prob_code / episode histogram
@@ -449,9 +451,10 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
                       : (io.reward_a_f32 || io.reward_b_f32 || io.finished || io.last_return) ? 1 : 0;
         const dim3 b(kBlock);
 #define SWAR_ARGS P.state + c0, P.state_stride, off(io.act_a, c0), off(io.act_b, c0), (h->capturing ? P.tick_in : nullptr), cn, (unsigned long long)(h->tick - 1), Q
-#define SWAR_GO(OV, SV, PV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 1>), gh, b, 0, h->stream, SWAR_ARGS); \
-                                 else hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 0>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
-#define SWAR_SLIP(OV, PV) do { if (!h->slip) SWAR_GO(OV, 0, PV); else if (h->d_slip_step_lut) SWAR_GO(OV, 2, PV); else SWAR_GO(OV, 1, PV); } while (0)
+#define SWAR_GO(OV, SV, PV, XV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 1, XV>), gh, b, 0, h->stream, SWAR_ARGS); \
+                                     else hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 0, XV>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
+#define SWAR_SLIP(OV, PV) do { if (expl) SWAR_GO(OV, 0, PV, true); else if (!h->slip) SWAR_GO(OV, 0, PV, false); \
+                               else if (h->d_slip_step_lut) SWAR_GO(OV, 2, PV, false); else SWAR_GO(OV, 1, PV, false); } while (0)
 #define SWAR_OUT(PV) do { if (out == 2) SWAR_SLIP(2, PV); else if (out == 1) SWAR_SLIP(1, PV); else SWAR_SLIP(0, PV); } while (0)
         // The kernel's byte offsets are 32-bit (soccer_kernels.hpp): a handle beyond kSwarLaunchLanes lanes is stepped by
         // several launches on the same tick, each handed its part of every stream; only the last one publishes the tick.
@@ -465,8 +468,8 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
                          (h->cfg.flags & SOCCER_F_STREAM_ACTIONS) ? 1u : 0u, P.policy_a, P.policy_b,
                          off(io.obs, c0), off(io.reward, c0), off(io.terminated, c0), off(io.truncated, c0), off(io.prob_code, c0),
                          off(io.final_obs, c0), off(io.reward_a_f32, c0), off(io.reward_b_f32, c0), off(io.finished, c0),
-                         off(io.last_return, c0)};
-            if (policy_only) SWAR_OUT(true); else SWAR_OUT(false);
+                         off(io.last_return, c0), off(io.u_step, c0), off(io.u_reset, c0)};
+            if (P.policy_a || P.policy_b) SWAR_OUT(true); else SWAR_OUT(false);
         }
 #undef SWAR_OUT
 #undef SWAR_SLIP
@@ -1494,26 +1497,30 @@ extern "C" int soccer_trajectory_returns(soccer_handle* h, int32_t n_steps, cons
     if (stride < (int64_t)h->P.n) return fail(h, SOCCER_E_INVALID, "soccer_trajectory_returns: stride must be >= n_lanes");
     if (!aligned(episode_count, 4)) return fail(h, SOCCER_E_INVALID, "soccer_trajectory_returns: episode_count must be 4-byte aligned");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (!h->d_traj_hist) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_traj_hist), 64));
-    HIP_TRY(h, hipMemsetAsync(h->d_traj_hist, 0, 64, h->stream));
+    const size_t slots = (size_t)h->grid_cap * 2;       // one u64[4] per workgroup of the (at most two) launches
+    if (!h->d_traj_hist) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_traj_hist), slots * 4 * sizeof(unsigned long long)));
     const unsigned long long n = h->P.n;
     const bool vec = stride % 4 == 0 && aligned(reward, 4) && aligned(terminated, 4) && aligned(truncated, 4) &&
                      aligned(last_return, 4) && aligned(episode_count, 16);
     const unsigned long long n4 = vec ? (n & ~3ull) : 0ull;
-    TrajIO io{reward, terminated, truncated, (long long)stride, n_steps, n4, last_return, episode_count, h->d_traj_hist};
-    if (n4) hipLaunchKernelGGL(trajectory_returns_kernel<true>, dim3(grid_for(h, n4 >> 2)), dim3(kBlock), 0, h->stream, io);
+    TrajIO io{reward, terminated, truncated, (long long)stride, n_steps, n4, last_return, episode_count, h->d_traj_hist, 0u};
+    uint32_t used = 0;
+    if (n4) { used = (uint32_t)grid_for(h, n4 >> 2); hipLaunchKernelGGL(trajectory_returns_kernel<true>, dim3(used), dim3(kBlock), 0, h->stream, io); }
     if (n4 < n) {               // ragged tail, or everything when a stream is not dword-aligned: a lane per thread
         TrajIO t = io;
-        t.reward += n4; t.terminated += n4; t.truncated += n4; t.n = n - n4;
+        t.reward += n4; t.terminated += n4; t.truncated += n4; t.n = n - n4; t.slot0 = used;
         t.last_return = off(last_return, n4); t.episode_count = off(episode_count, n4);
-        hipLaunchKernelGGL(trajectory_returns_kernel<false>, dim3(grid_for(h, t.n)), dim3(kBlock), 0, h->stream, t);
+        const uint32_t g2 = (uint32_t)grid_for(h, t.n);
+        hipLaunchKernelGGL(trajectory_returns_kernel<false>, dim3(g2), dim3(kBlock), 0, h->stream, t);
+        used += g2;
     }
     HIP_TRY(h, hipGetLastError());
     if (hist) {
-        unsigned long long out[3] = {0, 0, 0};
-        HIP_TRY(h, hipMemcpyAsync(out, h->d_traj_hist, sizeof out, hipMemcpyDeviceToHost, h->stream));
+        std::vector<unsigned long long> part((size_t)used * 4);
+        HIP_TRY(h, hipMemcpyAsync(part.data(), h->d_traj_hist, part.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        hist[0] = out[0]; hist[1] = out[1]; hist[2] = out[2];
+        hist[0] = hist[1] = hist[2] = 0;
+        for (uint32_t b = 0; b < used; ++b) for (int k = 0; k < 3; ++k) hist[k] += part[(size_t)b * 4 + k];
     }
     return SOCCER_OK;
 }

@@ -151,6 +151,11 @@ __device__ __forceinline__ unsigned long long block_tick(unsigned long long tick
 // A caller-supplied uniform.  Values outside [0,1) (and NaN) make every running sum compare
 // "not greater", which categorical_sample resolves to index 0 — same as u = 0.
 __device__ __forceinline__ double sane_uniform(double u) { return ((u >= 0.0) && (u < 1.0)) ? u : 0.0; }
+// The same for the float64 walk over a slip list (slip_prob > 0), whose total may round to 1 + 2^-52: there the reference's
+// argmax(cumsum(p) > u) picks the LAST entry for u == 1.0 (np_random.random() never returns it, but a caller's array may hold
+// it), so the upper side is left to the walk — which answers index 0 when no running sum exceeds u — and only negative values
+// and NaN are folded onto 0 (every first entry is positive: index 0 either way).
+__device__ __forceinline__ double sane_uniform_walk(double u) { return (u >= 0.0) ? u : 0.0; }
 
 // ---- LDS-resident rule tables ------------------------------------------------------------------
 struct Tables {
@@ -740,7 +745,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
             }
             Draw d = draw_from_word<SLIP>(w, tick);
             if (EXPLICIT_U) {
-                if (IO.u_step) { const double u = sane_uniform(IO.u_step[i0 + j]); d.u = u; d.top2 = (uint32_t)(u * 4.0); }
+                // (fetching the group's four uniforms ahead of this rolled loop was tried in round 4: slower on the slip walk,
+                // 17.1 -> 20.4 us per launch at 2^20 lanes — sixteen more live registers; slip 0 takes step_kernel_swar<.., EXPL>)
+                if (IO.u_step) { const double raw = IO.u_step[i0 + j]; const double u = sane_uniform(raw); d.u = SLIP ? sane_uniform_walk(raw) : u; d.top2 = (uint32_t)(u * 4.0); }
                 if (IO.u_reset) d.reset2 = (uint32_t)(sane_uniform(IO.u_reset[i0 + j]) * 4.0);
             }
             // byte j of every packed stream: one v_bfe_u32 each (the offset 8*j is wave-uniform)
@@ -958,6 +965,7 @@ struct SwarParams {
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs;                          // OUT == 2
     float* reward_a_f32; float* reward_b_f32; uint8_t* finished; int8_t* last_return;   // OUT >= 1
+    const double* u_step; const double* u_reset;   // EXPL: caller-supplied uniforms (16-byte aligned; either may be nullptr: Philox then)
 };
 
 // OUT — which outputs the instantiation can write (every pointer may still be NULL):
@@ -983,8 +991,13 @@ struct SwarParams {
 // Without SLIP the thread's block is the one of tick >> 3 and the lanes' draws are this tick's nibbles (swar::rand_nibble).
 // POLICY: single-agent handles — the fixed side's action is looked up from its int8[nS] policy by the observation of
 // the CURRENT tuple (four byte gathers per thread, behind the state loads); that side's action stream may be NULL.
+// EXPL (slip_prob == 0 handles): the caller's own uniforms (batched_step_ex's u_step / u_reset: the reference-RNG replay path,
+// e.g. a host that keeps the reference's MT19937 streams) replace the lanes' Philox bits.  Every list probability is 1, 1/2
+// or 1/4 and the ISD is uniform over 4 or 2 entries, so floor(4u) IS the reference's first-exceeds decision for any double
+// (:395, :414; values outside [0, 1) and NaN select index 0 like argmax of an all-False array): four doubles per stream and
+// thread, two 16-byte loads each, issued with the state loads; round 3 sent these calls to the per-lane kernel (11.0 us).
 constexpr unsigned long long kSwarLaunchLanes = 1ull << 30;   // 4 bytes per lane (the float rewards) * 2^30 lanes: offsets below 2^32
-template <int OUT, int SLIPM = 0, bool POLICY = false, int GEO = 0>
+template <int OUT, int SLIPM = 0, bool POLICY = false, int GEO = 0, bool EXPL = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_in, unsigned long long state_stride,
                                                            const int8_t* act_a, const int8_t* act_b,
                                                            const unsigned long long* tick_in,
@@ -992,6 +1005,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
                                                            const SwarParams Q) {
     constexpr bool FULL = OUT == 2;
     constexpr bool SLIP = SLIPM != 0;
+    static_assert(!EXPL || SLIPM == 0, "caller-supplied uniforms take the byte-parallel step only at slip_prob == 0");
     static_assert(kSlipStepBuckets == 64 * 16 && kSlipThresholds <= 64, "one 16-byte piece of the table per lane of a wave");
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     const bool active = (g << 2) < n;                                // n is a multiple of 4 here
@@ -1047,11 +1061,24 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         S.ps = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 4 * state_stride, ls)));
         S.tt = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(AT(sp + 5 * state_stride, ls)));
     }
+    // EXPL: the four lanes' uniforms, as floor(4u) (two bits each) — behind the state loads, ahead of the Philox block
+    uint32_t xq = 0u, xr = 0u;
+    if (EXPL && active) {
+        auto quarters = [&](const double* base) {
+            const double2 a = *reinterpret_cast<const double2*>(base + i0), b = *reinterpret_cast<const double2*>(base + i0 + 2);
+            return (uint32_t)(sane_uniform(a.x) * 4.0) | ((uint32_t)(sane_uniform(a.y) * 4.0) << 8) |
+                   ((uint32_t)(sane_uniform(b.x) * 4.0) << 16) | ((uint32_t)(sane_uniform(b.y) * 4.0) << 24);
+        };
+        if (Q.u_step) xq = quarters(Q.u_step);
+        if (Q.u_reset) xr = quarters(Q.u_reset);
+    }
     // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
     const unsigned long long tick = tick_in ? *tick_in : tick_val;
     const unsigned long long q = (Q.lane_offset + i0) >> 2;     // the thread's 4 lanes are exactly one Philox block
     const unsigned long long bt = block_tick<SLIP>(tick);
-    const Philox4 blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), Q.key0, Q.key1);
+    Philox4 blk{{0u, 0u, 0u, 0u}};
+    if (!EXPL || !Q.u_step || !Q.u_reset)                           // (wave-uniform; both uniforms supplied: no block is needed)
+        blk = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)bt, (uint32_t)(bt >> 32), Q.key0, Q.key1);
     const uint8_t* slip_lut = nullptr; const uint32_t* slip_thr = nullptr;
     if (SLIPM == 2) {                                                // park the table: all 64 lanes, whether their lanes exist or not
         __shared__ __attribute__((aligned(16))) uint32_t s_slip[SLIPM == 2 ? kBlock / 64 : 1][SLIPM == 2 ? kSlipStepLdsWords : 4];
@@ -1089,6 +1116,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
             rnd = swar::Rand4{k4 << 6, swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> Q.C.isd_shift};
         } else {
             rnd = swar::rand_nibble(Q.C.isd_shift, (uint32_t)tick & 7u, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
+            if (EXPL) {                                              // Rand4: the quarter in bits 7, 6 of each byte; the reset draw, shifted
+                if (Q.u_step) rnd.kq = xq << 6;
+                if (Q.u_reset) rnd.rs = xr >> Q.C.isd_shift;
+            }
         }
         // Frozen lanes and goal tuples exist only without auto-reset or after a state injection; a thread none of whose lanes is
         // in either condition (nearly every thread of an auto-resetting handle) takes the step without the code for them —
@@ -1264,7 +1295,7 @@ __global__ __launch_bounds__(64) void scalar_kernel(const KernelParams P, const 
             if (P.policy_b) b_now = (uint32_t)(uint8_t)P.policy_b[s_now];
         }
         const double u = sane_uniform(IO.u_step);
-        const Draw d{u, (uint32_t)(u * 4.0), (uint32_t)(sane_uniform(IO.u_reset) * 4.0), 0u};
+        const Draw d{SLIP ? sane_uniform_walk(IO.u_step) : u, (uint32_t)(u * 4.0), (uint32_t)(sane_uniform(IO.u_reset) * 4.0), 0u};
         (void)lane_step<SLIP>(T, P, L, a_now, b_now, d, R);
     }
     uint8_t* sw = P.state;
@@ -2012,7 +2043,7 @@ struct TrajIO {
     const int8_t* reward; const uint8_t* terminated; const uint8_t* truncated;
     long long stride; int32_t n_steps; unsigned long long n;
     int8_t* last_return; int32_t* episode_count;       // nullable
-    unsigned long long* hist;                           // device u64[3]: return -1, 0, +1 (atomics)
+    unsigned long long* hist; uint32_t slot0;           // device u64[slots][4]: per-workgroup counts of returns -1, 0, +1, from slot `slot0`
 };
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void trajectory_returns_kernel(const TrajIO IO) {
@@ -2023,18 +2054,36 @@ __global__ __launch_bounds__(kBlock) void trajectory_returns_kernel(const TrajIO
         if (VEC) {
             const unsigned long long i0 = g << 2;
             uint32_t last = 0u, c8 = 0u, cnt[4] = {0u, 0u, 0u, 0u};
-            for (int s = 0; s < IO.n_steps; ++s) {
-                const long long row = (long long)s * IO.stride;
-                const uint32_t r = *reinterpret_cast<const uint32_t*>(IO.reward + row + i0);
-                const uint32_t f = *reinterpret_cast<const uint32_t*>(IO.terminated + row + i0) |
-                                   *reinterpret_cast<const uint32_t*>(IO.truncated + row + i0);
+            // eight rows in flight per thread (24 independent dword loads, streamed once: non-temporal; the scheduling barrier
+            // keeps them ahead of the arithmetic): a load per row and wait ran at 1.2 TB/s (profiles/r04_a: 174 us for T = 64)
+            constexpr int U = 8;
+            auto row_of = [&](uint32_t r, uint32_t f) {
                 const uint32_t nz = ((f | ((f & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;     // 0 / 1 per byte
                 const uint32_t m = nz * 255u, rm = r & m;
                 last = (last & ~m) | rm;
                 c8 += nz;
-                if ((s & 127) == 127) { for (int j = 0; j < 4; ++j) cnt[j] += (c8 >> (8 * j)) & 0xffu; c8 = 0u; }
                 fin_t += (uint32_t)__builtin_popcount(nz); nz_t += (uint32_t)__builtin_popcount(rm & 0x01010101u);
                 neg_t += (uint32_t)__builtin_popcount(rm & 0x80808080u);
+            };
+            int s0 = 0;
+            for (; s0 + U <= IO.n_steps; s0 += U) {
+                uint32_t r[U], ft[U], fr[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const long long row = (long long)(s0 + k) * IO.stride;
+                    r[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.reward + row + i0));
+                    ft[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.terminated + row + i0));
+                    fr[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(IO.truncated + row + i0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < U; ++k) row_of(r[k], ft[k] | fr[k]);
+                if ((s0 & 127) == 120) { for (int j = 0; j < 4; ++j) cnt[j] += (c8 >> (8 * j)) & 0xffu; c8 = 0u; }   // every 128 rows: no byte overflows
+            }
+            for (; s0 < IO.n_steps; ++s0) {                                              // the last n_steps % 8 rows (c8 gains < 8 here)
+                const long long row = (long long)s0 * IO.stride;
+                row_of(*reinterpret_cast<const uint32_t*>(IO.reward + row + i0),
+                       *reinterpret_cast<const uint32_t*>(IO.terminated + row + i0) | *reinterpret_cast<const uint32_t*>(IO.truncated + row + i0));
             }
             for (int j = 0; j < 4; ++j) cnt[j] += (c8 >> (8 * j)) & 0xffu;
             if (IO.last_return) *reinterpret_cast<uint32_t*>(IO.last_return + i0) = last;
@@ -2052,11 +2101,16 @@ __global__ __launch_bounds__(kBlock) void trajectory_returns_kernel(const TrajIO
             if (IO.episode_count) IO.episode_count[g] = (int32_t)cnt;
         }
     }
+    // one private slot per workgroup, summed by the host (atomics of 4 096 waves on three words of one line were 120 of the
+    // 170 us this kernel took at T = 64: profiles/r04_a_kernel_stats_other.csv)
+    __shared__ uint32_t part[kBlock / 64][3];
     const uint32_t tot = wave_sum(fin_t), nzs = wave_sum(nz_t), neg = wave_sum(neg_t);
-    if ((threadIdx.x & 63u) == 0u && tot) {
-        if (neg) atomicAdd(IO.hist, (unsigned long long)neg);
-        if (tot - nzs) atomicAdd(IO.hist + 1, (unsigned long long)(tot - nzs));
-        if (nzs - neg) atomicAdd(IO.hist + 2, (unsigned long long)(nzs - neg));
+    if ((threadIdx.x & 63u) == 0u) { part[threadIdx.x >> 6][0] = neg; part[threadIdx.x >> 6][1] = tot - nzs; part[threadIdx.x >> 6][2] = nzs - neg; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long v = 0ull;
+        for (int wv = 0; wv < kBlock / 64; ++wv) v += part[wv][threadIdx.x];
+        IO.hist[(size_t)(IO.slot0 + blockIdx.x) * 4 + threadIdx.x] = v;
     }
 }
 

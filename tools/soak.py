@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the HIP path against the CPU oracle (run on the GPU box): random pitch, slip, seed, lane count,
-lane offset, auto-reset, single steps (lean / full) and fused rollouts (streams / sampled / mixed policies / single-agent),
+lane offset, auto-reset, single steps (lean / full; Philox or caller-supplied uniforms) and fused rollouts (streams / sampled / mixed policies / single-agent),
 every lane of every step compared (incl. the ABI-2 gym outputs, aligned and not).  Usage: tools/soak.py [seconds [seed]]"""
 import sys, time
 import numpy as np
@@ -37,13 +37,28 @@ while time.time() - t0 < budget:
         rfa = b.alloc(n + 4, np.float32).fill(7) if gym and rng.random() < 0.8 else None
         rfb = b.alloc(n + 4, np.float32).fill(7) if gym and rng.random() < 0.8 else None
         dn = b.alloc(n + 4, np.uint8).fill(7) if gym and rng.random() < 0.8 else None
+        # caller-supplied uniforms (the reference-RNG replay path): either stream, sometimes only 8-byte aligned (per-lane kernel),
+        # with the values the first-exceeds rule is sensitive to mixed in (dyadic thresholds, 0, 1 - ulp, out of range, NaN)
+        expl = rng.random() < 0.3
+        ush = int(rng.choice([0, 0, 1])) if expl else 0
+        du = b.alloc(n + 2, np.float64) if expl and rng.random() < 0.8 else None
+        dr = b.alloc(n + 2, np.float64) if expl and (du is None or rng.random() < 0.7) else None
+        edge = np.array([0.0, 0.25, 0.5, 0.75, 0.2499999999999999, 0.4999999999999999, 1.0 - 2.0 ** -53, 2.0 ** -53, 1.0, -0.5, np.nan, 7.0])
         for k in range(int(rng.integers(5, 60))):
             a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
             aa.upload(a[0]); ab.upload(a[1])
+            us = ur = None
+            if du is not None:
+                us = np.where(rng.random(n) < 0.2, edge[rng.integers(0, len(edge), n)], rng.random(n))
+                du.upload(np.concatenate([np.zeros(ush), us, np.zeros(2 - ush)]))
+            if dr is not None:
+                ur = np.where(rng.random(n) < 0.2, edge[rng.integers(0, len(edge), n)], rng.random(n))
+                dr.upload(np.concatenate([np.zeros(ush), ur, np.zeros(2 - ush)]))
             b.step(aa, ab, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin,
                    reward_a_f32=None if rfa is None else rfa.ptr + 4 * sh, reward_b_f32=None if rfb is None else rfb.ptr + 4 * sh,
-                   finished=None if dn is None else dn.ptr + sh)
-            c = o.step(a[0], a[1])
+                   finished=None if dn is None else dn.ptr + sh,
+                   u_step=None if du is None else du.ptr + 8 * ush, u_reset=None if dr is None else dr.ptr + 8 * ush)
+            c = o.step(a[0], a[1], u_step=us, u_reset=ur)
             assert np.array_equal(obs.download(), c["obs"]) and np.array_equal(rew.download(), c["reward"]), "step " + tag
             assert np.array_equal(te.download(), c["terminated"]) and np.array_equal(tr.download(), c["truncated"]), "step flags " + tag
             if full:
