@@ -167,3 +167,17 @@ def test_host_file_communicator_three_ranks(tmp_path):
         assert s == [6, 60, 21] and m == [2.0, 0.0]
         assert g == [[100.0, 0.0], [101.0, 0.5], [102.0, 1.0]]
         assert left <= 2 * world
+
+
+def test_under_torch_distributed_run_two_ranks_rendezvous():
+    """The driver's N > 1 command line: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.  The ranks are
+    children of the elastic agent (same parent, same MASTER_PORT), which is all the host-file / RCCL-id rendezvous needs."""
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29557", BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["rank_sum"] == 3.0
