@@ -664,7 +664,7 @@ def main():
                          "bound_note": "bytes counted at the L2<->fabric boundary (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits "
                                        "are included, and the ~%d MB working set of a run fits the 256 MB Infinity Cache when K is small"
                                        % (working_set >> 20),
-                         "kernel": "soccer::step_kernel_swar<0, %s, false, 1>" % ("2" if args.slip else "0"),   # as rocprofv3 prints it (slips the table form does not cover: 1)
+                         "kernel": "soccer::step_kernel_swar<0, %s, false, 1, false>" % ("2" if args.slip else "0"),   # as rocprofv3 prints it (slips the table form does not cover: 1)
                          "frac_from": "ms_per_step (host wall clock, the clock `value` uses)",
                          "achieved_device": achieved_dev, "frac_device": achieved_dev / HBM_PEAK_GBPS,
                          "launch_us": launch_s * 1e6, "device_region_us": ev_ms * 1e3,

@@ -134,7 +134,7 @@ def report(tag):
     L = []
     w = L.append
     t = json.load(open(os.path.join(PROF, "traffic.json")))
-    step = "soccer::step_kernel_swar<0, 0, false, 1>"
+    step_prefix = "soccer::step_kernel_swar<0, 0, false, 1"     # (+ ", false>" since round 4's EXPL parameter)
     w("# %s — generated by `tools/collect_profile.py report %s` from the tracked files `profiles/%s_*` and `profiles/traffic.json`" % (tag, tag, tag))
     w("")
     w("Do not edit: every figure below is recomputed from those files (`tests/test_profiles_report.py` regenerates this file and compares).")
@@ -145,6 +145,7 @@ def report(tag):
     w("")
     # ---- 1. the step kernel's clocks -------------------------------------------------------------------------------------
     ks, kf, kd = _stats(tag, "kernel_stats"), _stats(tag, "kernel_stats_full"), _stats(tag, "kernel_stats_driver_shape")
+    step = next((k for k in ks if k.startswith(step_prefix) and not k.endswith(", true>")), step_prefix + ">")
     un, ds, pr = _line(tag, "bench_unprofiled"), _line(tag, "bench_driver_shape"), _line(tag, "bench")
     sq = {}
     p = os.path.join(PROF, "%s_sq_counters.csv" % tag)
@@ -222,13 +223,18 @@ def report(tag):
     bytes_of = [("step_kernel_swar<0,", 19 * N, "19 B/lane"), ("step_kernel_swar<1,", 23 * N, "23 B/lane (lean vector env)"),
                 ("step_kernel_swar<2,", 31 * N, "31 B/lane (full vector env)"),
                 ("reset_kernel_swar<false", 6 * N, "6 B/lane (+2 with the observation out)"), ("reset_kernel_swar<true", 15 * N, "1 + 6 + 6 + 2 B/lane"),
-                ("trajectory_returns_kernel", (3 * 64 + 5) * N, "3 B/lane-step x 64 + 5 B/lane")]
+                ("trajectory_returns_kernel", None, "")]
     for name, lab in (("kernel_stats", "step-only"), ("kernel_stats_full", "default"), ("kernel_stats_slip0p2", "slip 0.2"),
                       ("kernel_stats_venv", "vector-env leg"), ("kernel_stats_other", "profile_others.py")):
         tab = _stats(tag, name)
         for k in sorted(tab):
             r = tab[k]
             nb, what = next(((b, wh) for pre, b, wh in bytes_of if pre in k.replace("soccer::", "")), (None, ""))
+            if "trajectory_returns_kernel" in k:                      # its T is the pass's: the bench line's K, or profile_others.py's 64
+                bl = _line(tag, {"kernel_stats": "bench", "kernel_stats_full": "bench_full", "kernel_stats_slip0p2": "bench_slip_unprofiled"}.get(name, ""))
+                T = bl["steps"] if bl else (64 if name == "kernel_stats_other" else None)
+                if T:
+                    nb, what = (3 * T + 5) * N, "3 B/lane-step x %d + 5 B/lane" % T
             if name == "kernel_stats_full" and k in _stats(tag, "kernel_stats"):
                 continue
             fr = "%s / %s" % ("%.3f" % (nb / (float(r["AverageNs"]) * 1e-9) / PEAK), "%.3f" % (nb / (float(r["MinNs"]) * 1e-9) / PEAK)) if nb else ""
