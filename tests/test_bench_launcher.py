@@ -181,3 +181,65 @@ def test_under_torch_distributed_run_two_ranks_rendezvous():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["rank_sum"] == 3.0
+
+
+class _FakeLib:
+    """Stands in for libsoccer_hip's soccer_comm_unique_id in the CPU test of RcclComm's bring-up."""
+    def soccer_comm_unique_id(self, buf):
+        for i in range(128):
+            buf[i] = (i * 7 + 3) & 0xff
+        return 0
+
+    def soccer_last_error(self, h):
+        return b""
+
+
+class _FakeBatch:
+    def __init__(self, log, collective):
+        self.lib, self.h, self.log, self.collective = _FakeLib(), None, log, collective
+
+    def comm_init(self, world, rank, uid):
+        self.log.append(("init", world, rank, bytes(uid)))
+        self.collective.barrier()              # ncclCommInitRank is collective: it returns when every rank has joined
+
+    def comm_barrier(self):
+        self.log.append(("barrier",))
+
+    def comm_destroy(self):
+        self.log.append(("destroy",))
+
+
+def _rccl_bringup_worker(rank, world, directory, q):
+    sys.path.insert(0, ROOT)
+    import time
+    from gym_soccer_littman94_amd.comm import HostComm, RcclComm
+    if rank == 0:
+        time.sleep(0.5)                        # the other ranks are already polling for the id when rank 0 publishes it
+    log = []
+    c = RcclComm(_FakeBatch(log, HostComm(rank, world, timeout=30.0, directory=directory + "_collective")), rank, world,
+                 timeout=30.0, directory=directory)
+    c.close()
+    q.put((rank, log))
+
+
+def test_rccl_bring_up_hands_every_rank_the_same_unique_id(tmp_path):
+    """The part of the N > 1 path no single GPU can run: ranks != 0 learn rank 0's 128-byte id through the rendezvous file,
+    ignore a stale file of an earlier job, and every rank calls comm_init(world, rank, id) then the first barrier.  (RCCL itself is
+    replaced by a recording fake; the real library runs in tests/test_gpu_comm.py with world = 1.)"""
+    import multiprocessing as mp
+    import time
+    d = tmp_path / "rdv"; d.mkdir(); (tmp_path / "rdv_collective").mkdir()
+    stale = d / "rccl_unique_id"; stale.write_bytes(b"\x00" * 128)
+    old = time.time() - 3600
+    os.utime(str(stale), (old, old))           # an hour old: a job that died before cleaning up
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_rccl_bringup_worker, args=(r, world, str(d), q)) for r in range(world)]
+    for p in ps: p.start()
+    got = dict(q.get(timeout=60) for _ in range(world))
+    for p in ps: p.join(30)
+    uid = bytes((i * 7 + 3) & 0xff for i in range(128))
+    for r in range(world):
+        assert got[r][0] == ("init", world, r, uid), got[r][:1]
+        assert got[r][1] == ("barrier",) and got[r][-1] == ("destroy",)
