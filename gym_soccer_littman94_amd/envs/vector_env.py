@@ -374,36 +374,61 @@ class VectorSoccerEnv:
                 "device io expects contiguous torch.int8 CUDA tensors of shape [n_steps, num_envs]"
         if self.strict and b.peek_misuse():           # (like step(): what the launches completed so far have raised)
             self._raise_on_misuse()
-        bufs = self._roll_bufs.get(T) if hasattr(self, "_roll_bufs") else None
-        if bufs is None:
-            if not hasattr(self, "_roll_bufs"):
-                self._roll_bufs = {}
-                u16 = getattr(t, "uint16", t.int16)
-                self._r_fin = t.zeros(n, dtype=u16, device=d); self._r_code = t.zeros(n, dtype=t.uint8, device=d)
-                self._r_finished = t.zeros(n, dtype=t.uint8, device=d)
-            u16 = getattr(t, "uint16", t.int16)
-            bufs = (t.empty((T, n), dtype=u16, device=d), t.empty((T, n), dtype=t.int8, device=d),
-                    t.empty((T, n), dtype=t.uint8, device=d), t.empty((T, n), dtype=t.uint8, device=d))
-            self._roll_bufs = {T: bufs}               # one set: a new length replaces the old buffers
-        obs, rew, term, trunc = bufs
-        mix = self._mix_tables(mixed_policies, lambda tab: t.from_numpy(tab.view(np.int16)).to(d)) if sample else {}
-        self._rollout_launch(T, a, bb, sample, mix, obs, rew, term, trunc, self._r_fin, self._r_code, self._r_finished,
-                             lambda x, k: None if x is None else x[k])
+        plan = getattr(self, "_roll_plan", None)
+        if plan is None or plan["T"] != T:
+            plan = self._roll_plan = self._make_roll_plan(T)      # one set of buffers: a new length replaces the old one
+        obs, rew, term, trunc = plan["bufs"]
+        for lz in plan["lazy"]:                       # what the caller looked at after the previous rollout
+            lz.invalidate()
+        if sample:
+            mix = self._mix_tables(mixed_policies, lambda tab: t.from_numpy(tab.view(np.int16)).to(d))
+            b.rollout(T, sample_actions=True, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
+                      mix_a=mix.get("player_a"), mix_b=mix.get("player_b"))
+            return plan["ret_sampled"]
+        # T - 1 fused steps, then the last one as a full step: two ctypes calls on argument blocks built once
+        pa = a.data_ptr() if a is not None else None
+        pb = bb.data_ptr() if bb is not None else None
+        if T > 1:
+            ra = plan["rollout_args"]; ra.act_a = pa; ra.act_b = pb
+            code = plan["rollout_call"](b.h, plan["rollout_ref"])
+            if code:
+                b._check(code)
+        sa = plan["step_args"]; last = (T - 1) * n
+        sa.act_a = None if pa is None else pa + last
+        sa.act_b = None if pb is None else pb + last
+        code = plan["step_call"](b.h, plan["step_ref"])
+        if code:
+            b._check(code)
+        return plan["ret"]
+
+    def _make_roll_plan(self, T):
+        import ctypes
+        from .._lib import RolloutArgs, StepArgs
+        t, n, d, b = self._torch, self.num_envs, self._dev, self._batch
+        u16 = getattr(t, "uint16", t.int16)
+        obs = t.empty((T, n), dtype=u16, device=d); rew = t.empty((T, n), dtype=t.int8, device=d)
+        term = t.empty((T, n), dtype=t.uint8, device=d); trunc = t.empty((T, n), dtype=t.uint8, device=d)
+        fin = t.zeros(n, dtype=u16, device=d); code = t.zeros(n, dtype=t.uint8, device=d); finished = t.zeros(n, dtype=t.uint8, device=d)
         ags = self.return_agent
         term_b, trunc_b = term.view(t.bool), trunc.view(t.bool)
         thunks = {}
         if 'player_a' in ags: thunks['player_a'] = lambda: rew.to(t.float32)
         if 'player_b' in ags: thunks['player_b'] = lambda: 0.0 - rew.to(t.float32)          # :400-402, :243-244
-        infos = {"reward_int8": rew}
-        if sample:
-            infos = _Lazy({"_final_observation": lambda: term_b[-1] | trunc_b[-1]}, infos)
-        else:
-            code = self._r_code
-            lazy = _LazyInfo(lambda: self._prob[code.long()])
-            infos.update({ag: lazy for ag in ags})
-            infos["final_observation"] = {ag: self._r_fin for ag in ags}
-            infos["_final_observation"] = self._r_finished.view(t.bool)
-        return ({ag: obs for ag in ags}, _Lazy(thunks), {ag: term_b for ag in ags}, {ag: trunc_b for ag in ags}, infos)
+        rewards = _Lazy(thunks)
+        p_lazy = _LazyInfo(lambda: self._prob[code.long()])
+        infos = {"reward_int8": rew, "final_observation": {ag: fin for ag in ags}, "_final_observation": finished.view(t.bool)}
+        infos.update({ag: p_lazy for ag in ags})
+        infos_sampled = _Lazy({"_final_observation": lambda: term_b[-1] | trunc_b[-1]}, {"reward_int8": rew})
+        O = {ag: obs for ag in ags}; TE = {ag: term_b for ag in ags}; TR = {ag: trunc_b for ag in ags}
+        last = T - 1
+        rollout_args = RolloutArgs(max(T - 1, 1), 0, None, None, n, obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), n,
+                                   None, None, None, None)
+        step_args = StepArgs(None, None, None, None, obs[last].data_ptr(), rew[last].data_ptr(), term[last].data_ptr(), trunc[last].data_ptr(),
+                             code.data_ptr(), fin.data_ptr(), None, None, None, finished.data_ptr())
+        return {"T": T, "bufs": (obs, rew, term, trunc), "keep": (fin, code, finished), "lazy": (rewards, p_lazy, infos_sampled),
+                "ret": (O, rewards, TE, TR, infos), "ret_sampled": (O, rewards, TE, TR, infos_sampled),
+                "rollout_args": rollout_args, "rollout_ref": ctypes.byref(rollout_args), "rollout_call": b.lib.batched_rollout,
+                "step_args": step_args, "step_ref": ctypes.byref(step_args), "step_call": b.lib.batched_step_ex}
 
     @property
     def reward_int8(self):
