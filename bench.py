@@ -100,13 +100,13 @@ def _cpulist(text):
     return out
 
 
-def gpu_local_cpus(local_rank, local_world):
+def gpu_local_cpus(local_rank, local_world, sysfs="/sys", allowed=None):
     """CPUs this rank should run on: those of the NUMA node its GPU hangs off, cut into disjoint slices for the ranks that
     share the node (a spinning host thread per rank: 15 % of a ~100 us timed region is host time).  Read from sysfs — the KFD
     topology lists the GPUs in the order HIP numbers them — so it can run before the process makes its first GPU call.
     Returns (cpus or None, note)."""
     try:
-        topo = "/sys/class/kfd/kfd/topology/nodes"
+        topo = sysfs + "/class/kfd/kfd/topology/nodes"
         gpus = []
         for node in sorted(os.listdir(topo), key=int):
             try:
@@ -124,14 +124,14 @@ def gpu_local_cpus(local_rank, local_world):
             return None, "no GPU in the KFD topology"
 
         def numa_of(minor):
-            n = int(open("/sys/class/drm/renderD%d/device/numa_node" % minor).read())
+            n = int(open(sysfs + "/class/drm/renderD%d/device/numa_node" % minor).read())
             return max(n, 0)                   # -1: a single-node machine
         nodes = [numa_of(m) for m in gpus[:local_world]] if local_world <= len(gpus) else None
         if nodes is None or local_rank >= len(nodes):
             return None, "more local ranks than GPUs (rehearsal): not pinned"
         mine = nodes[local_rank]
-        allowed = set(os.sched_getaffinity(0))
-        cpus = [c for c in _cpulist(open("/sys/devices/system/node/node%d/cpulist" % mine).read()) if c in allowed]
+        allowed = set(os.sched_getaffinity(0)) if allowed is None else set(allowed)
+        cpus = [c for c in _cpulist(open(sysfs + "/devices/system/node/node%d/cpulist" % mine).read()) if c in allowed]
         sharers = [r for r in range(len(nodes)) if nodes[r] == mine]
         per = len(cpus) // len(sharers)
         if per < 2:
@@ -448,7 +448,12 @@ def main():
 
     # (names bound before the clock starts: at K = 20 the region is ~100 us and a Python attribute chain is ~0.3 us)
     graph_launch, handle, check = lib.soccer_graph_launch, b.h, b._check
-    device_sync = b.sync                         # hipStreamSynchronize on the handle's stream: the only stream with work
+    sync_call = lib.soccer_sync
+
+    def device_sync():                           # hipStreamSynchronize on the handle's stream: the only stream with work
+        rc = sync_call(handle)
+        if rc:
+            check(rc)
     rc_box, ev_box = [0], [None]
     if graph is not None:
         def launch():

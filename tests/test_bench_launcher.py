@@ -243,3 +243,43 @@ def test_rccl_bring_up_hands_every_rank_the_same_unique_id(tmp_path):
     for r in range(world):
         assert got[r][0] == ("init", world, r, uid), got[r][:1]
         assert got[r][1] == ("barrier",) and got[r][-1] == ("destroy",)
+
+
+def test_rank_placement_on_a_two_socket_eight_gpu_topology(tmp_path):
+    """gpu_local_cpus against a made-up sysfs tree of the node the driver would use for the scaling run: two CPU nodes (KFD
+    nodes 0-1, no SIMDs), eight GPUs (KFD nodes 2-9) of which 0-3 hang off NUMA node 0 and 4-7 off node 1, 32 CPUs per node with
+    hyper-thread siblings listed as a second range.  Every rank must land on its GPU's node, in a slice no other rank has."""
+    bench = _load_bench()
+    root = tmp_path / "sys"
+    for node in range(10):
+        d = root / "class/kfd/kfd/topology/nodes" / str(node); d.mkdir(parents=True)
+        gpu = node - 2
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n"
+                                      % ((16, 0, -1) if node < 2 else (0, 1024, 128 + gpu)))
+        if node >= 2:
+            r = root / ("class/drm/renderD%d/device" % (128 + gpu)); r.mkdir(parents=True)
+            (r / "numa_node").write_text("%d\n" % (0 if gpu < 4 else 1))
+    for nn, cl in ((0, "0-15,32-47"), (1, "16-31,48-63")):
+        d = root / ("devices/system/node/node%d" % nn); d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    everything = set(range(64))
+    seen = {}
+    for r in range(8):
+        cpus, note = bench.gpu_local_cpus(r, 8, sysfs=str(root), allowed=everything)
+        assert cpus and len(cpus) == 8, note
+        node_cpus = set(range(0, 16)) | set(range(32, 48)) if r < 4 else set(range(16, 32)) | set(range(48, 64))
+        assert set(cpus) <= node_cpus, (r, cpus, note)
+        for c in cpus:
+            assert c not in seen, "ranks %d and %d share CPU %d" % (seen[c], r, c)
+            seen[c] = r
+    assert len(seen) == 64
+    # one rank on an eight-GPU node: the whole node of GPU 0; an affinity mask that leaves a rank one CPU: not pinned, and said so
+    cpus, _ = bench.gpu_local_cpus(0, 1, sysfs=str(root), allowed=everything)
+    assert sorted(cpus) == sorted(set(range(0, 16)) | set(range(32, 48)))
+    cpus, note = bench.gpu_local_cpus(5, 8, sysfs=str(root), allowed={16, 17, 18})
+    assert cpus is None and "not pinned" in note
+    # a GPU node this process may not read (another tenant's): skipped, the visible GPUs keep HIP's numbering
+    os.chmod(str(root / "class/kfd/kfd/topology/nodes/2/properties"), 0)
+    if os.geteuid() != 0:                        # (root reads anything)
+        cpus, note = bench.gpu_local_cpus(3, 7, sysfs=str(root), allowed=everything)
+        assert set(cpus) <= set(range(16, 32)) | set(range(48, 64)), note          # visible GPU 3 = the host's GPU 4: NUMA node 1
