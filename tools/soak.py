@@ -44,8 +44,14 @@ while time.time() - t0 < budget:
         du = b.alloc(n + 2, np.float64) if expl and rng.random() < 0.8 else None
         dr = b.alloc(n + 2, np.float64) if expl and (du is None or rng.random() < 0.7) else None
         edge = np.array([0.0, 0.25, 0.5, 0.75, 0.2499999999999999, 0.4999999999999999, 1.0 - 2.0 ** -53, 2.0 ** -53, 1.0, -0.5, np.nan, 7.0])
+        # single-agent single steps (the fixed side acts on the current observation, :187-188), with and without the caller's uniforms
+        early_pol = rng.integers(0, 5, size=o.nS).astype(np.int8) if rng.random() < 0.2 else None
+        if early_pol is not None:
+            b.set_policy("player_b", early_pol)
         for k in range(int(rng.integers(5, 60))):
             a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+            if early_pol is not None:
+                a[1] = early_pol[cur]
             aa.upload(a[0]); ab.upload(a[1])
             us = ur = None
             if du is not None:
@@ -54,7 +60,7 @@ while time.time() - t0 < budget:
             if dr is not None:
                 ur = np.where(rng.random(n) < 0.2, edge[rng.integers(0, len(edge), n)], rng.random(n))
                 dr.upload(np.concatenate([np.zeros(ush), ur, np.zeros(2 - ush)]))
-            b.step(aa, ab, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin,
+            b.step(aa, None if early_pol is not None else ab, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin,
                    reward_a_f32=None if rfa is None else rfa.ptr + 4 * sh, reward_b_f32=None if rfb is None else rfb.ptr + 4 * sh,
                    finished=None if dn is None else dn.ptr + sh,
                    u_step=None if du is None else du.ptr + 8 * ush, u_reset=None if dr is None else dr.ptr + 8 * ush)
@@ -71,6 +77,8 @@ while time.time() - t0 < budget:
             if dn is not None:
                 assert np.array_equal(dn.download()[sh:sh + n], c["terminated"] | c["truncated"]), "finished " + tag
             cur = c["obs"]; lanes_steps += n
+        if early_pol is not None:
+            b.set_policy("player_b", None)
         for arr, fill in ((rfa, 0x07070707), (rfb, 0x07070707), (dn, 7)):       # nothing written outside [sh, sh + n)
             if arr is not None:
                 d = arr.download(); d = d.view(np.uint32) if d.dtype == np.float32 else d
