@@ -13,6 +13,7 @@ reductions (BASELINE configs[3]).  Two interchangeable backends 
 Ranks, world size and the rendezvous come from the environment torch.distributed.run sets (RANK, WORLD_SIZE, LOCAL_RANK,
 MASTER_PORT); `python bench.py --gpus N` sets the same variables for the ranks it starts itself.
 """
+import ctypes
 import os
 import time
 
@@ -129,7 +130,7 @@ class RcclComm:
         path = os.path.join(d, "rccl_unique_id")
         t_start = time.time()
         if self.rank == 0:
-            buf = (__import__("ctypes").c_uint8 * _lib.COMM_ID_BYTES)()
+            buf = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
             _lib.check(batch.lib, None, batch.lib.soccer_comm_unique_id(buf))
             uid = bytes(buf)
             _publish(path, uid)
