@@ -100,3 +100,18 @@ def test_no_cpu_fallback_without_a_device():
     from gym_soccer_littman94_amd import SoccerBatch
     with pytest.raises(_lib.SoccerHipError, match="no CPU path|no HIP device|failed"):
         SoccerBatch(16)
+
+
+def test_c_example_builds_from_the_header_alone_and_fails_loudly_without_a_device(tmp_path):
+    """examples/host.c is plain C against include/soccer_hip.h (gcc -Wall -Wextra -Werror, no HIP headers).  On a box without a GPU
+    it must stop at soccer_create with the library's message — there is no CPU path to fall back to."""
+    import subprocess
+    import torch
+    exe = str(tmp_path / "host_c")
+    lib_dir = os.path.join(ROOT, "gym_soccer_littman94_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host.c"),
+                           "-o", exe, "-L", lib_dir, "-lsoccer_hip", "-Wl,-rpath," + lib_dir])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_c_host.py runs it")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no CPU path" in r.stderr, (r.returncode, r.stderr)
