@@ -116,21 +116,28 @@ def gpu_local_cpus(local_rank, local_world, sysfs="/sys", allowed=None):
             props = dict(l.split(None, 1) for l in text.splitlines() if " " in l)
             if int(props.get("simd_count", "0")) > 0:
                 gpus.append(int(props.get("drm_render_minor", "-1")))
+        narrowed = False
         for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
             v = os.environ.get(var)
             if v and all(x.strip().isdigit() for x in v.split(",")):
-                gpus = [gpus[int(x)] for x in v.split(",") if int(x) < len(gpus)]
+                gpus = [gpus[int(x)] for x in v.split(",") if int(x) < len(gpus)]; narrowed = True
         if not gpus:
             return None, "no GPU in the KFD topology"
 
         def numa_of(minor):
             n = int(open(sysfs + "/class/drm/renderD%d/device/numa_node" % minor).read())
             return max(n, 0)                   # -1: a single-node machine
+        allowed = set(os.sched_getaffinity(0)) if allowed is None else set(allowed)
+        if len(gpus) == 1 and local_world > 1 and narrowed:
+            # every rank isolated behind its own *_VISIBLE_DEVICES: this rank's GPU is the one it sees; who else shares the
+            # node is not knowable from here, so the whole node it is
+            node = numa_of(gpus[0])
+            cpus = [c for c in _cpulist(open(sysfs + "/devices/system/node/node%d/cpulist" % node).read()) if c in allowed]
+            return (cpus or None), "NUMA node %d of the one visible GPU (render minor %d), unsliced" % (node, gpus[0])
         nodes = [numa_of(m) for m in gpus[:local_world]] if local_world <= len(gpus) else None
         if nodes is None or local_rank >= len(nodes):
             return None, "more local ranks than GPUs (rehearsal): not pinned"
         mine = nodes[local_rank]
-        allowed = set(os.sched_getaffinity(0)) if allowed is None else set(allowed)
         cpus = [c for c in _cpulist(open(sysfs + "/devices/system/node/node%d/cpulist" % mine).read()) if c in allowed]
         sharers = [r for r in range(len(nodes)) if nodes[r] == mine]
         per = len(cpus) // len(sharers)
@@ -374,10 +381,12 @@ def main():
     if lib.soccer_device_count(ctypes.byref(ndev)) != 0 or ndev.value < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to bench)")
     host_comm = args.comm == "host"
-    if not host_comm and local_rank >= ndev.value:
+    # a launcher that isolates every rank behind its own *_VISIBLE_DEVICES sees ONE device, number 0, whatever LOCAL_RANK says
+    isolated = ndev.value == 1 and local_rank > 0 and any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if not host_comm and not isolated and local_rank >= ndev.value:
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible (one rank per GPU; --comm host "
                          "rehearses more ranks than GPUs)" % (rank, local_rank, ndev.value))
-    dev_index = local_rank % ndev.value if host_comm else local_rank
+    dev_index = 0 if isolated else (local_rank % ndev.value if host_comm else local_rank)
 
     N, K, W = args.lanes, args.steps, args.warmup
     lane_lo, lane_hi = shard_range(world * N, rank, world)      # contiguous global lane ids of this rank

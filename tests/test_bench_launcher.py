@@ -278,6 +278,13 @@ def test_rank_placement_on_a_two_socket_eight_gpu_topology(tmp_path):
     assert sorted(cpus) == sorted(set(range(0, 16)) | set(range(32, 48)))
     cpus, note = bench.gpu_local_cpus(5, 8, sysfs=str(root), allowed={16, 17, 18})
     assert cpus is None and "not pinned" in note
+    # a launcher that hides all GPUs but one from every rank: the rank's GPU is the one it sees (its node, unsliced)
+    os.environ["HIP_VISIBLE_DEVICES"] = "6"
+    try:
+        cpus, note = bench.gpu_local_cpus(6, 8, sysfs=str(root), allowed=everything)
+    finally:
+        del os.environ["HIP_VISIBLE_DEVICES"]
+    assert sorted(cpus) == sorted(set(range(16, 32)) | set(range(48, 64))) and "unsliced" in note
     # a GPU node this process may not read (another tenant's): skipped, the visible GPUs keep HIP's numbering
     os.chmod(str(root / "class/kfd/kfd/topology/nodes/2/properties"), 0)
     if os.geteuid() != 0:                        # (root reads anything)
