@@ -101,14 +101,15 @@ class HostComm:
         batch._check(batch.lib.soccer_memcpy_h2d(batch.h, recv.ptr, flat.ctypes.data, flat.nbytes))
 
     def close(self):
+        """Last exchange, then every rank leaves a `done` mark: it will read nothing any more.  Rank 0 removes the directory once
+        all marks are there (no rank deletes a file another rank may still be reading)."""
         try:
             self.barrier()
-            mine = os.path.join(self.dir, "x%d_%d" % (self.seq, self.rank))
-            time.sleep(0.05)                # the others are reading this last file right now
-            if os.path.exists(mine):
-                os.unlink(mine)
+            _publish(os.path.join(self.dir, "done_%d" % self.rank), b"\x01")
             if self.rank == 0:
-                time.sleep(0.2)
+                deadline = time.monotonic() + min(self.timeout, 30.0)
+                for r in range(self.world):
+                    _await(os.path.join(self.dir, "done_%d" % r), 1, deadline)
                 for f in os.listdir(self.dir):
                     try:
                         os.unlink(os.path.join(self.dir, f))
