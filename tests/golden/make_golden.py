@@ -174,7 +174,7 @@ def dump_table(Env, width, height, slip, digest_only=False):
             isd_probs=np.asarray([p for p, _ in env.isd], dtype=np.float64),
             n_rows=np.int64(len(rows)), sha256=np.bytes_(sha), tuple_digest=per,
             list_length_hist=np.bincount(lens, minlength=37).astype(np.int64),
-            prob_sum=np.float64(probs.sum()), reference_ctor_seconds=np.float64(time.time() - t0))
+            prob_sum=np.float64(probs.sum()))            # (no timings in here: regenerating must reproduce the file byte for byte)
         print("  %s: %d rows (not stored), sha256 %s, nS=%d, %.1fs, %d KB" % (
             os.path.basename(out), len(rows), sha[:16], env.nS, time.time() - t0, os.path.getsize(out) // 1024))
         return env
