@@ -373,8 +373,10 @@ def dump_other_planners(env, policy, slip, learner, opponent):
         de_policy=stoch, de_init=init, de_v=pe_v, de_cc=np.int64(pe_cc), de0_v=pe0_v, de0_cc=np.int64(pe0_cc),
         mpi1_pi=np.asarray(m1[0], np.int64), mpi1_V=m1[1], mpi1_Q=m1[2], mpi1_counter=np.int64(m1[3]),
         mpi2_pi=np.asarray(m2[0], np.int64), mpi2_V=m2[1], mpi2_Q=m2[2], mpi2_counter=np.int64(m2[3]),
-        mpi3_pi=np.asarray(m3[0], np.int64), mpi3_V=m3[1], mpi3_Q=m3[2], mpi3_counter=np.int64(m3[3]),
-        reference_seconds=np.bytes_(json.dumps(sec)))
+        mpi3_pi=np.asarray(m3[0], np.int64), mpi3_V=m3[1], mpi3_Q=m3[2], mpi3_counter=np.int64(m3[3]))
+    # how long the reference took (for tools/planner_time.py): next to the fixture, not in it — the .npz must regenerate byte for byte
+    with open(out[:-4] + "_reference_seconds.json", "w") as f:
+        json.dump({k: round(v, 2) for k, v in sec.items()}, f)
     print("  %s: PI %d iterations, MPI counters %d / %d / %d, %s, %d KB"
           % (os.path.basename(out), pi_cc, m1[3], m2[3], m3[3], {k: round(v, 2) for k, v in sec.items()}, os.path.getsize(out) // 1024))
 
