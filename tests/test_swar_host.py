@@ -19,7 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def host(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("swar") / "libswar_host.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", "-o", so,
+    # SWAR_HOST_SANITIZE=1: the same tests with UndefinedBehaviorSanitizer in the host build of the byte-parallel rules
+    # (shifts, signed overflow, misaligned access ...; any report aborts the process) — sanitizers run on the CPU build only
+    san = ["-fsanitize=undefined", "-fno-sanitize-recover=all", "-g"] if os.environ.get("SWAR_HOST_SANITIZE") else []
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror"] + san + ["-o", so,
                            os.path.join(ROOT, "tests", "host", "swar_host.cpp")])
     L = C.CDLL(so)
     L.swar_step_host.restype = C.c_int
