@@ -62,7 +62,10 @@ extern "C" {
 #endif
 
 #define SOCCER_ABI_VERSION 3      /* 2: soccer_step_args grew reward_a_f32 / reward_b_f32 / finished
-                                     3: the bits -> uniform convention above (half-step offset; eight ticks per block at slip_prob == 0) */
+                                     3: the bits -> uniform convention above (half-step offset; eight ticks per block at slip_prob == 0)
+                                     (still 3: soccer_trajectory_returns and soccer_comm_* were ADDED, captured sequences may hold an odd
+                                     number of calls, and a caller's u >= 1 on a slip list follows the reference's comparison — nothing a
+                                     round-3 caller relied on changed, and checkpoints record this number for the RNG convention alone) */
 
 /* error codes */
 #define SOCCER_OK            0
