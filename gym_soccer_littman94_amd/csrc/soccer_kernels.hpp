@@ -321,14 +321,8 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
                                ((four & (d.m >= th.z)) ? 1u : 0u) + ((four & (d.m >= th.w)) ? 1u : 0u);
             sel = pick(A, B, p, R, k);
         } else if constexpr (!INT_ONLY) {
-        // each player has only three distinct moves (intended + two orthogonals): 6 table reads serve
-        // all nine combinations
-        uint32_t cellA[3], cellB[3];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            cellA[v] = moved(T, P, A, p ^ 1u, slip_move(aa, v));
-            cellB[v] = moved(T, P, B, p, slip_move(ab, v));
-        }
+        // the slipped move of variant v as a run-time value (slip_move with a constant v is the same table)
+        auto slip_move_rt = [](uint32_t a, uint32_t v) { return v == 0u ? a : (((v == 1u ? 0x12430u : 0x21340u) >> (4u * a)) & 7u); };
         // (1) Fast decision.  The list's running sums are, up to rounding, the cumulative weights of the
         // active combinations (P.B, summed on the host in the reference's order) plus multiples of the
         // combination's own q; the true float64 sums differ from these nominal values by < 1e-14 (at most
@@ -347,10 +341,14 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         }
         near_thr |= idx >= P.nb;
         uint32_t sel_c = (uint32_t)((P.act_pack >> (4u * idx)) & 0xfull), sel_k = 0u;
+        uint32_t cA_sel, cB_sel;                                        // the cells the SELECTED combination's moves reach
         {
+            // the fast decision needs the move table for ONE combination: two reads (round 4; it used to fetch the three distinct
+            // moves of both players up front for the walk below, six dependent gathers on every lane: 17.1 us per launch at 2^20 lanes)
             const uint32_t va = (VA2 >> (2u * sel_c)) & 3u, vb = (VB2 >> (2u * sel_c)) & 3u, cl = (CL2 >> (2u * sel_c)) & 3u;
-            const uint32_t cA = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
-            const uint32_t cB = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
+            const uint32_t cA = moved(T, P, A, p ^ 1u, slip_move_rt(aa, va));
+            const uint32_t cB = moved(T, P, B, p, slip_move_rt(ab, vb));
+            cA_sel = cA; cB_sel = cB;
             const uint32_t kind = in_goal ? (uint32_t)K_MOVE : classify(A, B, cA, cB, aa, ab).kind;
             const uint32_t n = kind == K_COIN ? 2u : (kind == K_FOUR ? 4u : 1u);
             const double wq = SOCCER_WEIGHT_OF(cl);
@@ -366,6 +364,13 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
         // over the combinations in reference order, each contributing 1, 2 or 4 equal entries; record
         // WHICH entry (combination c, outcome k) is the first to exceed u.
         if (near_thr) {
+            // each player has only three distinct moves (intended + two orthogonals): 6 table reads serve all nine combinations
+            uint32_t cellA[3], cellB[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                cellA[v] = moved(T, P, A, p ^ 1u, slip_move(aa, v));
+                cellB[v] = moved(T, P, B, p, slip_move(ab, v));
+            }
             double acc = 0.0;
             bool found = false;
             int first_c = -1;                                           // wave-uniform (weights are)
@@ -391,14 +396,14 @@ __device__ __forceinline__ bool lane_step(const Tables& T, const KernelParams& P
                 acc = end;
             }
             if (!found) { sel_c = (uint32_t)(first_c < 0 ? 0 : first_c); sel_k = 0u; }   // argmax of all-False is 0
+            const uint32_t va = (VA2 >> (2u * sel_c)) & 3u, vb = (VB2 >> (2u * sel_c)) & 3u;
+            cA_sel = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
+            cB_sel = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
         }
 #undef SOCCER_WEIGHT_OF
         // the selected combination
-        const uint32_t va = (VA2 >> (2u * sel_c)) & 3u, vb = (VB2 >> (2u * sel_c)) & 3u;
         cls = (CL2 >> (2u * sel_c)) & 3u;
-        const uint32_t sA_ = va == 0u ? cellA[0] : (va == 1u ? cellA[1] : cellA[2]);
-        const uint32_t sB_ = vb == 0u ? cellB[0] : (vb == 1u ? cellB[1] : cellB[2]);
-        sel = pick(A, B, p, classify(A, B, sA_, sB_, aa, ab), sel_k);
+        sel = pick(A, B, p, classify(A, B, cA_sel, cB_sel, aa, ab), sel_k);
         }
     }
     sel.A = in_goal ? A : sel.A; sel.B = in_goal ? B : sel.B; sel.p = in_goal ? p : sel.p;
