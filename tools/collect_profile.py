@@ -86,6 +86,7 @@ def fold(src, tag):
                  algorithmic_bytes_per_launch=ALGO, kernel=k, FETCH_SIZE_KB_mean=means[(k, "FETCH_SIZE")], WRITE_SIZE_KB_mean=means[(k, "WRITE_SIZE")],
                  step_kernel_hbm_bytes_per_launch=(2 * means[(k, "FETCH_SIZE")] + means[(k, "WRITE_SIZE")]) * 1024)
         json.dump(t, open(tf, "w"), indent=1)
+        json.dump(t, open(os.path.join(PROF, "%s_traffic.json" % tag), "w"), indent=1)      # the tag's own copy: what `report <tag>` reads
     rows, waves = [["kernel", "counter", "dispatches", "mean_per_dispatch", "per_wave"]], {}
     aggs = []
     for sq in ("sq2", "sq1", "sq_slip"):
@@ -133,9 +134,10 @@ def _frac(us):
 def report(tag):
     L = []
     w = L.append
-    t = json.load(open(os.path.join(PROF, "traffic.json")))
+    own = os.path.join(PROF, "%s_traffic.json" % tag)           # (traffic.json itself moves on to the latest capture)
+    t = json.load(open(own if os.path.exists(own) else os.path.join(PROF, "traffic.json")))
     step_prefix = "soccer::step_kernel_swar<0, 0, false, 1"     # (+ ", false>" since round 4's EXPL parameter)
-    w("# %s — generated by `tools/collect_profile.py report %s` from the tracked files `profiles/%s_*` and `profiles/traffic.json`" % (tag, tag, tag))
+    w("# %s — generated by `tools/collect_profile.py report %s` from the tracked files `profiles/%s_*`" % (tag, tag, tag))
     w("")
     w("Do not edit: every figure below is recomputed from those files (`tests/test_profiles_report.py` regenerates this file and compares).")
     w("Capture: `tools/profile_run.sh %s` on one MI355X (2^20 lanes, 5x4 pitch, slip 0 unless stated), folded by `tools/collect_profile.py fold`." % tag)
@@ -259,8 +261,8 @@ def report(tag):
                 w("| `%s` | %.1f | %.1f | %.2f |" % (k[:100], m[k]["FETCH_SIZE"], m[k]["WRITE_SIZE"], (2 * m[k]["FETCH_SIZE"] + m[k]["WRITE_SIZE"]) * 1024 / 1e6))
         if t.get("build") == tag:
             w("")
-            w("Step kernel: %.2f MB measured against %.2f MB algorithmic = **%.3f x** (`traffic.json`, what `bench.py` reports as `roofline.traffic`)."
-              % (t["step_kernel_hbm_bytes_per_launch"] / 1e6, ALGO / 1e6, t["step_kernel_hbm_bytes_per_launch"] / ALGO))
+            w("Step kernel: %.2f MB measured against %.2f MB algorithmic = **%.3f x** (`%s_traffic.json`; `traffic.json` = the latest capture's copy, what `bench.py` reports as `roofline.traffic`)."
+              % (t["step_kernel_hbm_bytes_per_launch"] / 1e6, ALGO / 1e6, t["step_kernel_hbm_bytes_per_launch"] / ALGO, tag))
         w("")
     # ---- 5. SQ counters -----------------------------------------------------------------------------------------------------
     if sq:
