@@ -87,6 +87,11 @@ class _LazyInfo(_Lazy):
 
 class VectorSoccerEnv:
     metadata = {"render_modes": []}
+    # what code written against gym 0.26's `gym.vector.VectorEnv` looks for besides reset / step / the four spaces
+    is_vector_env = True
+    render_mode = None
+    spec = None
+    closed = False
 
     def __init__(self, num_envs, width=5, height=4, slip_prob=0.0, seed=0, autoreset=True,
                  device=0, lane_offset=0, max_episode_steps=100, io="numpy", strict=True,
@@ -477,9 +482,50 @@ class VectorSoccerEnv:
     def batch(self):
         return self._batch
 
+    @property
+    def unwrapped(self):
+        return self
+
+    # gym.vector.VectorEnv's asynchronous pair and its reset counterpart: the launch IS asynchronous with device io (nothing is
+    # synchronised until a result is read); with numpy io the work happens in the *_wait call
+    def step_async(self, actions):
+        self._pending_actions = actions
+        if self.io == "device":
+            self._pending_result = self.step(actions)
+
+    def step_wait(self, **kwargs):
+        assert getattr(self, "_pending_actions", None) is not None, "step_wait() without step_async()"
+        actions, self._pending_actions = self._pending_actions, None
+        if self.io == "device":
+            out, self._pending_result = self._pending_result, None
+            return out
+        return self.step(actions)
+
+    def reset_async(self, seed=None, options=None):
+        self._pending_reset = (seed, options)
+
+    def reset_wait(self, seed=None, options=None, **kwargs):
+        s, o = getattr(self, "_pending_reset", None) or (seed, options)
+        self._pending_reset = None
+        return self.reset(seed=s, options=o)
+
+    def close_extras(self, **kwargs):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __repr__(self):
+        return "VectorSoccerEnv(num_envs=%d, %dx%d, slip_prob=%g, io=%r)" % (self.num_envs, self.width - 2, self.height, self.slip_prob, self.io)
+
     def close(self):
         """Frees the handle.  strict mode: a misuse raised by the last steps (device io reports up to 4 steps late, see step())
         is reported here at the latest — after the handle is gone, as the reference's assert would have been (:376, :393)."""
+        self.closed = True
         flags = 0
         if self.strict and self._batch.h:
             try:

@@ -535,3 +535,24 @@ def test_make_ids():
     v.close()
     with pytest.raises(KeyError):
         gsa.make("WalkFive-v0")
+
+
+def test_vector_env_has_the_rest_of_gyms_vector_surface():
+    """step_async / step_wait, reset_async / reset_wait, is_vector_env, unwrapped, closed, the context manager: what wrappers
+    written against gym 0.26's gym.vector.VectorEnv look for (the reference itself has no vector env)."""
+    n = 256
+    rng = np.random.default_rng(2)
+    with VectorSoccerEnv(n, slip_prob=0.2, seed=4) as v, VectorSoccerEnv(n, slip_prob=0.2, seed=4) as w:
+        assert v.is_vector_env and v.unwrapped is v and not v.closed and v.render_mode is None and "num_envs=256" in repr(v)
+        v.reset_async(seed=9); o1, _ = v.reset_wait()
+        o2, _ = w.reset(seed=9)
+        np.testing.assert_array_equal(o1["player_a"], o2["player_a"])
+        for _ in range(5):
+            a = {"player_a": rng.integers(0, 5, n), "player_b": rng.integers(0, 5, n)}
+            v.step_async(a); r1 = v.step_wait()
+            r2 = w.step(a)
+            for x, y in zip(r1[:4], r2[:4]):
+                np.testing.assert_array_equal(x["player_a"], y["player_a"])
+        with pytest.raises(AssertionError, match="without step_async"):
+            v.step_wait()
+    assert v.closed and w.closed
