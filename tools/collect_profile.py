@@ -232,6 +232,15 @@ def report(tag):
         for k in sorted(tab):
             r = tab[k]
             nb, what = next(((b, wh) for pre, b, wh in bytes_of if pre in k.replace("soccer::", "")), (None, ""))
+            if "step_kernel_swar<0" in k and k.endswith(", true>"):          # EXPL: + the two float64 uniform streams
+                nb, what = 35 * N, "19 + 16 B/lane (caller-supplied uniforms)"
+            if "rollout_swar_kernel<0," in k:                                 # action streams in, four trajectories out, state once
+                bl = _line(tag, {"kernel_stats_full": "bench_full", "kernel_stats_slip0p2": "bench_slip_unprofiled", "kernel_stats_venv": "venv_profiled"}.get(name, ""))
+                T = (bl.get("fused_rollout") or bl.get("rollout") or {}).get("steps_fused") if bl else None
+                if T and name == "kernel_stats_venv":
+                    T -= 1                                                    # VectorSoccerEnv.rollout: T - 1 fused steps + one full step
+                if T:
+                    nb, what = (7 * T + 12) * N, "7 B/lane-step x %d + 12 B/lane" % T
             if "trajectory_returns_kernel" in k:                      # its T is the pass's: the bench line's K, or profile_others.py's 64
                 bl = _line(tag, {"kernel_stats": "bench", "kernel_stats_full": "bench_full", "kernel_stats_slip0p2": "bench_slip_unprofiled"}.get(name, ""))
                 T = bl["steps"] if bl else (64 if name == "kernel_stats_other" else None)
