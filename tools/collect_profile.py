@@ -253,6 +253,8 @@ def report(tag):
     if others:
         w("")
         w("`profile_others.py` launched, at 2^20 lanes: " + "; ".join("%s x %d" % (k, v) for k, v in others.get("launches", {}).items()) + ".")
+        w("(It re-uses the same buffers for all 100 launches of a kind: those working sets — 30 to 40 MB — stay in the 256 MB Infinity Cache, so a")
+        w("fraction in its rows is bytes over time against the HBM peak, served from the cache, and can exceed 1.)")
     w("")
     # ---- 4. PMC traffic -----------------------------------------------------------------------------------------------------
     p = os.path.join(PROF, "%s_pmc_summary.csv" % tag)
