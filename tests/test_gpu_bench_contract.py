@@ -56,3 +56,29 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert len(d["per_rank"]) == 2 and {x["rank"] for x in d["per_rank"]} == {0, 1}
     assert abs(d["ms_per_step"] * 1e3 * K - max(x["wall_us"] for x in d["per_rank"])) < 1e-6       # the job's time is the slowest rank's
     assert d["episodes"]["gathered_last_returns"] == 2 * N and "REHEARSAL" in d["timed_region"]
+
+
+def test_two_real_ranks_when_the_box_has_two_gpus_else_a_loud_refusal():
+    """`python bench.py --gpus 2` with the real communicator (RCCL through soccer_comm_*).  On a box with >= 2 GPUs this IS the
+    two-rank RCCL run (shards in global lane order, per-rank clocks, no collective in the region); on a one-GPU box rank 1 must
+    refuse before any collective can hang, and the parent must stop rank 0 (which is waiting for it in the RCCL bring-up)."""
+    import ctypes
+    import time
+    from gym_soccer_littman94_amd import _lib
+    n = ctypes.c_int()
+    assert _lib.load().soccer_device_count(ctypes.byref(n)) == 0
+    N, K = 1 << 16, 8
+    flags = ["--gpus", "2", "--steps", str(K), "--warmup", "2", "--lanes", str(N), "--no-cpu-baseline", "--rollout", "0", "--rank-deadline", "120"]
+    if n.value >= 2:
+        d = _run(*flags)
+        assert d["n_gpus"] == 2 and d["config"]["host"]["comm"] == "rccl" and len(d["per_rank"]) == 2
+        assert d["episodes"]["gathered_last_returns"] == 2 * N and "REHEARSAL" not in d["timed_region"]
+        return
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, *flags], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "only 1 are visible" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert time.monotonic() - t0 < 100
