@@ -335,6 +335,8 @@ def main():
                     help="system: the image's ROCm runtime (/opt/rocm); torch: the older runtime bundled with PyTorch (what a "
                          "process that imports torch gets; A/B runs)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to its GPU's NUMA-local cores")
+    ap.add_argument("--isolated-devices", action="store_true",
+                    help="every rank has been given its own *_VISIBLE_DEVICES by the launcher and sees exactly one GPU: use device 0")
     ap.add_argument("--leg", choices=["main", "vector-env"], default="main", help=argparse.SUPPRESS)
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
@@ -381,8 +383,9 @@ def main():
     if lib.soccer_device_count(ctypes.byref(ndev)) != 0 or ndev.value < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to bench)")
     host_comm = args.comm == "host"
-    # a launcher that isolates every rank behind its own *_VISIBLE_DEVICES sees ONE device, number 0, whatever LOCAL_RANK says
-    isolated = ndev.value == 1 and local_rank > 0 and any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    # --isolated-devices: a launcher that hides all GPUs but one from every rank (its own *_VISIBLE_DEVICES per rank): each rank then
+    # sees ONE device, number 0, whatever LOCAL_RANK says.  Never inferred: a box that shows the whole job one GPU looks the same.
+    isolated = args.isolated_devices and ndev.value == 1
     if not host_comm and not isolated and local_rank >= ndev.value:
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible (one rank per GPU; --comm host "
                          "rehearses more ranks than GPUs)" % (rank, local_rank, ndev.value))
