@@ -92,7 +92,9 @@ def test_rccl_communicator_one_rank_through_the_c_abi(tmp_path):
 def test_torch_distributed_nccl_one_rank():
     """the torch.distributed helpers of distributed.py on backend "nccl" (= RCCL): 1-rank init + all_gather_into_tensor +
     all_reduce (tools/rccl_smoke.py, promoted to a test)"""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_smoke.py")], capture_output=True, text=True, timeout=600, env=env)
