@@ -44,6 +44,11 @@ class RolloutArgs(C.Structure):
                 ("mix_a", C.c_void_p), ("mix_b", C.c_void_p)]
 
 
+class RolloutExtra(C.Structure):
+    """soccer_rollout_extra"""
+    _fields_ = [("final_obs", C.c_void_p), ("prob_code", C.c_void_p)]
+
+
 class ScalarIO(C.Structure):
     """soccer_scalar_io"""
     _fields_ = [("row_a", C.c_int8), ("col_a", C.c_int8), ("row_b", C.c_int8), ("col_b", C.c_int8),
@@ -74,6 +79,7 @@ PROTOTYPES = {
     "batched_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "batched_step_ex": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
     "batched_rollout": (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs)]),
+    "batched_rollout_ex": (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs), C.POINTER(RolloutExtra)]),
     "batched_step_host": (C.c_int, [C.c_void_p, C.POINTER(StepArgs)]),
     "batched_reset_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "soccer_staging": (C.c_int, [C.c_void_p, C.POINTER(StagingView)]),

@@ -296,11 +296,16 @@ class SoccerBatch:
 
     def rollout(self, n_steps, act_a=None, act_b=None, act_stride=0, sample_actions=False, obs=None,
                 reward=None, terminated=None, truncated=None, out_stride=0, return_sum=None,
-                episode_count=None, mix_a=None, mix_b=None):
+                episode_count=None, mix_a=None, mix_b=None, final_obs=None, prob_code=None):
+        """batched_rollout; with final_obs / prob_code ([T][n] like the four result trajectories) batched_rollout_ex."""
         a = RolloutArgs(int(n_steps), 1 if sample_actions else 0, _ptr(act_a), _ptr(act_b), int(act_stride),
                         _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated), int(out_stride),
                         _ptr(return_sum), _ptr(episode_count), _ptr(mix_a), _ptr(mix_b))
-        self._check(self.lib.batched_rollout(self.h, C.byref(a)))
+        if final_obs is None and prob_code is None:
+            self._check(self.lib.batched_rollout(self.h, C.byref(a)))
+        else:
+            x = _lib.RolloutExtra(_ptr(final_obs), _ptr(prob_code))
+            self._check(self.lib.batched_rollout_ex(self.h, C.byref(a), C.byref(x)))
 
     def trajectory_returns(self, n_steps, reward, terminated, truncated, stride, last_return=None, episode_count=None, hist=True):
         """soccer_trajectory_returns: one pass over [n_steps][n] result trajectories (device) -> per-lane return of the most recently

@@ -554,14 +554,18 @@ static void launch_rollout(soccer_handle* h, const KernelParams& P, const Rollou
     if (dyn) launch_rollout2<E, true>(h, P, io); else launch_rollout2<E, false>(h, P, io);
 }
 
-extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
+extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) { return batched_rollout_ex(h, a, nullptr); }
+
+extern "C" int batched_rollout_ex(soccer_handle* h, const soccer_rollout_args* a, const soccer_rollout_extra* x) {
     if (!h) return fail(nullptr, SOCCER_E_INVALID, "handle is NULL");
     if (!a || a->n_steps < 1) return fail(h, SOCCER_E_INVALID, "batched_rollout: n_steps must be >= 1");
     if (!a->sample_actions && ((!a->act_a && !h->P.policy_a) || (!a->act_b && !h->P.policy_b)))
         return fail(h, SOCCER_E_INVALID, "batched_rollout: an action stream is required for every player without a fixed policy (or sample_actions)");
     if (!a->sample_actions && a->act_stride < (int64_t)h->P.n)
         return fail(h, SOCCER_E_INVALID, "batched_rollout: act_stride must be >= n_lanes");
-    const bool any_out = a->obs || a->reward || a->terminated || a->truncated;
+    uint16_t* x_fin = x ? x->final_obs : nullptr; uint8_t* x_code = x ? x->prob_code : nullptr;
+    const bool any_out = a->obs || a->reward || a->terminated || a->truncated || x_fin || x_code;
+    if (!aligned(x_fin, 2)) return fail(h, SOCCER_E_INVALID, "batched_rollout_ex: final_obs must be 2-byte aligned");
     if (any_out && a->out_stride < (int64_t)h->P.n)
         return fail(h, SOCCER_E_INVALID, "batched_rollout: out_stride must be >= n_lanes");
     if (!aligned(a->obs, 2) || !aligned(a->return_sum, 4) || !aligned(a->episode_count, 4) ||
@@ -572,7 +576,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
     auto ok = [&](int e) {
         const bool strides = (a->sample_actions || a->act_stride % e == 0) && (!any_out || a->out_stride % e == 0);
         return strides && aligned(a->act_a, e) && aligned(a->act_b, e) && aligned(a->reward, e) &&
-               aligned(a->terminated, e) && aligned(a->truncated, e) && aligned(a->obs, 2 * e) &&
+               aligned(a->terminated, e) && aligned(a->truncated, e) && aligned(a->obs, 2 * e) && aligned(x_code, e) && aligned(x_fin, 2 * e) &&
                aligned(a->return_sum, 4 * e) && aligned(a->episode_count, 4 * e);
     };
     while (E > 1 && !ok(E)) E = E == 4 ? 1 : E / 2;
@@ -588,7 +592,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
         RolloutIO io{ns, a->sample_actions, a->mix_a, a->mix_b, a->act_a ? a->act_a + ao : nullptr, a->act_b ? a->act_b + ao : nullptr,
                      (long long)a->act_stride, a->obs ? a->obs + oo : nullptr, a->reward ? a->reward + oo : nullptr,
                      a->terminated ? a->terminated + oo : nullptr, a->truncated ? a->truncated + oo : nullptr,
-                     (long long)a->out_stride, a->return_sum, a->episode_count};
+                     (long long)a->out_stride, a->return_sum, a->episode_count, x_fin ? x_fin + oo : nullptr, x_code ? x_code + oo : nullptr};
         // the byte-parallel rollout: every pitch that fits the byte arithmetic, slip 0 or an exact integer slip decision
         // (a lane count that is not a multiple of 4: the byte-parallel kernel over the first n & ~3 lanes, the one to three
         // left over through the per-lane kernel on the same ticks, like batched_step's ragged tail)
@@ -635,12 +639,14 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
             io.act_a = off(io0.act_a, lane0); io.act_b = off(io0.act_b, lane0); io.obs = off(io0.obs, lane0); io.reward = off(io0.reward, lane0);
             io.terminated = off(io0.terminated, lane0); io.truncated = off(io0.truncated, lane0);
             io.return_sum = off(io0.return_sum, lane0); io.episode_count = off(io0.episode_count, lane0);
+            io.final_obs = off(io0.final_obs, lane0); io.prob_code = off(io0.prob_code, lane0);
             const uint64_t groups = cn >> 2;
             uint64_t blocks = (groups + kBlock - 1) / kBlock;
             if (blocks > (uint64_t)h->grid_cap) blocks = h->grid_cap;
             const dim3 g((unsigned)blocks), bl(kBlock);
-#define LAUNCH_G(DV, SV, GV) do { if (smem > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV, GV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-                                  hipLaunchKernelGGL((rollout_swar_kernel<DV, SV, GV>), g, bl, smem, h->stream, RS, io); } while (0)
+#define LAUNCH_F(DV, SV, GV, FV) do { if (smem > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_swar_kernel<DV, SV, GV, FV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+                                      hipLaunchKernelGGL((rollout_swar_kernel<DV, SV, GV, FV>), g, bl, smem, h->stream, RS, io); } while (0)
+#define LAUNCH_G(DV, SV, GV) do { if (io.final_obs || io.prob_code) LAUNCH_F(DV, SV, GV, true); else LAUNCH_F(DV, SV, GV, false); } while (0)
 #define LAUNCH_S(DV, SV) do { if (h->swar_c.small) LAUNCH_G(DV, SV, 1); else LAUNCH_G(DV, SV, 0); } while (0)
             // the action source as a compile-time shape (rollout_swar_group): streams / sampled uniformly / both sides from
             // mixed-policy tables / single-agent A or B / anything else
@@ -654,6 +660,7 @@ extern "C" int batched_rollout(soccer_handle* h, const soccer_rollout_args* a) {
 #undef LAUNCH_D
 #undef LAUNCH_S
 #undef LAUNCH_G
+#undef LAUNCH_F
             }
             if (n4 < n_all) {
                 KernelParams Q = h->P;

@@ -99,6 +99,7 @@ struct RolloutIO {
     const int8_t* act_a; const int8_t* act_b; long long act_stride;
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated; long long out_stride;
     int32_t* return_sum; int32_t* episode_count;
+    uint16_t* final_obs; uint8_t* prob_code;      // batched_rollout_ex: per-step [T][n] trajectories (row stride out_stride) or nullptr
 };
 
 // ---- Philox4x32-10 (Salmon et al. 2011; Random123 constants) ---------------------------------
@@ -1361,8 +1362,8 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         uint32_t words[E], awords[E];
         lane_words<E>(P, P.lane_offset + i0, block_tick<SLIP>(tick), 0u, words);
         if (sample) lane_words<E>(P, P.lane_offset + i0, tick, 1u, awords);
-        PackB<E> o_rew, o_term, o_trunc; PackH<E> o_obs;
-        o_rew.clear(); o_term.clear(); o_trunc.clear(); o_obs.clear();
+        PackB<E> o_rew, o_term, o_trunc, o_code; PackH<E> o_obs, o_fin;
+        o_rew.clear(); o_term.clear(); o_trunc.clear(); o_obs.clear(); o_code.clear(); o_fin.clear();
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const Draw d = draw_from_word<SLIP>(words[j], tick);
@@ -1388,6 +1389,7 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
             any_misuse |= lane_step<SLIP, true>(T, P, S.L[j], a, b, d, R);
             if (DYN) s_now[j] = R.obs;
             o_obs.put(j, R.obs); o_rew.put(j, (uint32_t)R.reward & 0xffu); o_term.put(j, R.term); o_trunc.put(j, R.trunc);
+            o_fin.put(j, R.final_obs); o_code.put(j, R.code);
             ret[j] += R.reward; eps[j] += (int32_t)R.finished; nonzero += (uint32_t)R.reward & 1u;
         }
         const long long off = (long long)s * IO.out_stride;
@@ -1395,6 +1397,8 @@ __device__ __forceinline__ void rollout_group(const Tables& T, const KernelParam
         if (IO.reward) o_rew.store_nt(IO.reward + off, i0);
         if (IO.terminated) o_term.store_nt(IO.terminated + off, i0);
         if (IO.truncated) o_trunc.store_nt(IO.truncated + off, i0);
+        if (IO.final_obs) o_fin.store_nt(IO.final_obs + off, i0);
+        if (IO.prob_code) o_code.store_nt(IO.prob_code + off, i0);
         aa = naa; ab = nab;
     }
     S.store(P, i0);
@@ -1490,7 +1494,7 @@ __device__ __forceinline__ uint32_t draw_b15(uint32_t wm) { return swar::perm(0u
 // Randomness (include/soccer_hip.h): with SLIP one step/reset block per tick; without, one block per EIGHT ticks — the
 // thread keeps it transposed (swar::transpose4) in p0..p3, p0 serving the current pair of ticks — which takes the Philox
 // rounds from ~45 to ~6 vector instructions per step; sampled actions take the lane's word of the tick's purpose-1 block.
-template <int DYNM, int SLIPM, bool GENERAL, int GEO>
+template <int DYNM, int SLIPM, bool GENERAL, int GEO, bool FULL = false>
 __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const RolloutIO& IO, const SlipSrc& slip,
                                                    const uint2* mix_a_in, const uint2* mix_b_in, const int8_t* pol_a_in, const int8_t* pol_b_in,
                                                    uint32_t* act_lds,
@@ -1636,7 +1640,7 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
             // was three v_cndmask_b32 every step, each several times the cost of a move (tools/labs/valu_rate_lab.hip).
             if (t & 1u) { asm volatile(""); p0 = p1; p1 = p2; p2 = p3; }
         }
-        swar::step4<GENERAL, false, SLIP, GEO, TRUSTED>(C, S, a4, b4, sa, sb, cls4, rnd, o);
+        swar::step4<GENERAL, FULL, SLIP, GEO, TRUSTED>(C, S, a4, b4, sa, sb, cls4, rnd, o);
         s_lo = o.obs_lo; s_hi = o.obs_hi;
         // the step's row of every stream as a uniform base (scalar registers) + this thread's 32-bit byte offset: stores of the
         // form v_off, data, s[base] (the offset passes through an empty asm per step, else the optimiser keeps one 64-bit
@@ -1648,6 +1652,11 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
         if (IO.reward) __builtin_nontemporal_store(o.rew, reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(IO.reward + row) + j0));
         if (IO.terminated) __builtin_nontemporal_store(o.term, reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(IO.terminated + row) + j0));
         if (IO.truncated) __builtin_nontemporal_store(o.trunc, reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(IO.truncated + row) + j0));
+        if (FULL) {     // batched_rollout_ex: what gym's vector convention reports per step next to the four streams
+            if (IO.final_obs) __builtin_nontemporal_store((unsigned long long)o.fin_lo | ((unsigned long long)o.fin_hi << 32),
+                                                          reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(IO.final_obs + row) + (j0 << 1)));
+            if (IO.prob_code) __builtin_nontemporal_store(o.code, reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(IO.prob_code + row) + j0));
+        }
         // finished episodes by return: a reward byte is 0x01 / 0xff only on the step that ends an episode
         fin_loc += (uint32_t)__builtin_popcount(o.finished & swar::K80);
         if (GENERAL) { nz_loc += (uint32_t)__builtin_popcount(o.rew & swar::K01); neg_loc += (uint32_t)__builtin_popcount(o.rew & swar::K80); }
@@ -1672,7 +1681,8 @@ __device__ __forceinline__ void rollout_swar_group(const RolloutSwar& R, const R
     neg_tot += GENERAL ? neg_loc : (neg_loc - nz_loc) / 7u;             // (pos + 8 neg) - (pos + neg) = 7 neg
 }
 
-template <int DYNM, int SLIPM, int GEO = 0>
+// FULL: also the per-step final_obs / prob_code trajectories (batched_rollout_ex; +3 B per env-step and the second observation index)
+template <int DYNM, int SLIPM, int GEO = 0, bool FULL = false>
 __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar R, const RolloutIO IO) {
     constexpr bool SLIP = SLIPM != 0;
     constexpr bool DYN = DYNM >= 2;          // the forms that look something up by the observation
@@ -1729,8 +1739,8 @@ __global__ __launch_bounds__(kBlock) void rollout_swar_kernel(const RolloutSwar 
         // any lane frozen, any player in a goal column (= a goal tuple), or no auto-reset: the general step
         const uint32_t edge = swar::is_zero(S.ca) | swar::is_zero(S.cb) | swar::is_zero(S.ca ^ R.C.Wm1x4) | swar::is_zero(S.cb ^ R.C.Wm1x4);
         const bool special = R.C.autoreset == 0u || (((S.ps << 6) | edge) & swar::K80) != 0u;
-        if (special) rollout_swar_group<DYNM, SLIPM, true, GEO>(R, IO, slip, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
-        else rollout_swar_group<DYNM, SLIPM, false, GEO>(R, IO, slip, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        if (special) rollout_swar_group<DYNM, SLIPM, true, GEO, FULL>(R, IO, slip, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
+        else rollout_swar_group<DYNM, SLIPM, false, GEO, FULL>(R, IO, slip, mix_a, mix_b, pol_a, pol_b, act_lds, i0, tick0, S, fin_tot, nz_tot, neg_tot, acc, frozen_any, bad_any);
         uint8_t* sw = R.state + i0;
         *reinterpret_cast<uint32_t*>(sw) = S.ra; *reinterpret_cast<uint32_t*>(sw + R.state_stride) = S.ca;
         *reinterpret_cast<uint32_t*>(sw + 2 * R.state_stride) = S.rb; *reinterpret_cast<uint32_t*>(sw + 3 * R.state_stride) = S.cb;

@@ -296,22 +296,23 @@ class VectorSoccerEnv:
 
     # ---------------------------------------------------------------------------------------------
     def rollout(self, n_steps, actions=None, sample_actions=False, mixed_policies=None):
-        """T = `n_steps` fused steps — by definition EXACTLY what T successive `step()` calls return, stacked over T (same
-        ticks, same auto-reset convention: soccer_simultaneous_env.py:397-408 per step) — in one or two launches instead of T:
-        `batched_rollout` keeps the state in registers for the first T - 1 steps and the last step is a full `batched_step`, so
-        that the last step's `infos` are there as after `step()`.
+        """T = `n_steps` fused steps in ONE launch — by definition EXACTLY what T successive `step()` calls return, stacked over T
+        (same ticks, same auto-reset convention: soccer_simultaneous_env.py:397-408 per step), infos included: `batched_rollout_ex`
+        keeps the state in registers and writes every step's row of every stream.
 
         actions  dict like step()'s, every value [T, num_envs] (device io: contiguous torch.int8 CUDA tensors; numpy io: integer
                  arrays, checked to be 0..4 on the host).  Single-agent mode: the learner's key only.
         sample_actions=True (actions None)  both players act uniformly at random, drawn in the kernel from the lanes' purpose-1
                  Philox words (include/soccer_hip.h); `mixed_policies` = {agent: [nS, 5] probabilities} samples that agent's
-                 action from its row of the current observation instead (BASELINE config 5).  All T steps are fused and `infos`
-                 then holds `_final_observation` only.
+                 action from its row of the current observation instead (BASELINE config 5).
 
         Returns (observations, rewards, terminated, truncated, infos): dicts per returned agent of [T, num_envs] arrays —
         uint16 observations, float32 rewards (device io: cast from the kernel's int8 trajectory on first access; the int8
-        trajectory of player A's reward is infos["reward_int8"]), bool flags — and the LAST step's infos.  The arrays are
-        buffers the env owns, one set per T, overwritten by the next rollout of the same length."""
+        trajectory of player A's reward is infos["reward_int8"]), bool flags — and infos stacked the same way:
+        infos["final_observation"][agent] [T, num_envs] (the observation before that step's auto-reset: what a learner
+        bootstraps from at a truncation), infos["_final_observation"] (= terminated | truncated), infos[agent]["p"] (on first
+        access).  With info=False (device io) the two info trajectories are not written (7 instead of 10 B per env-step).
+        The arrays are buffers the env owns, one set per T, overwritten by the next rollout of the same length."""
         assert not self._needs_reset, "Please reset the environment before taking a step"
         T, n, b = int(n_steps), self.num_envs, self._batch
         assert T >= 1, "n_steps must be >= 1"
@@ -324,7 +325,7 @@ class VectorSoccerEnv:
             a, bb = self._check_actions(actions)
         if self.io == "device":
             return self._rollout_device(T, a, bb, sample_actions, mixed_policies)
-        # ---- numpy io: host arrays in, host arrays out; same kernels, one upload and one download -------------------
+        # ---- numpy io: host arrays in, host arrays out; the same launch, one upload and one download --------------------
         dev = {}
         for key, x in (("a", a), ("b", bb)):
             if x is None:
@@ -335,22 +336,21 @@ class VectorSoccerEnv:
             dev[key] = b.alloc((T, n), np.int8).upload(x.astype(np.int8, copy=False))
         obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8)
         term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
-        fin = b.alloc(n, np.uint16); code = b.alloc(n, np.uint8)
+        fin = b.alloc((T, n), np.uint16); code = b.alloc((T, n), np.uint8)
         mix = self._mix_tables(mixed_policies, lambda t: b.alloc(t.shape, np.uint16).upload(t)) if sample_actions else {}
-        self._rollout_launch(T, dev.get("a"), dev.get("b"), sample_actions, mix, obs, rew, term, trunc, fin, code, None,
-                             lambda arr, k: None if arr is None else arr.row(k))
-        O, R = obs.download(), rew.download().astype(np.float32)
+        b.rollout(T, dev.get("a"), dev.get("b"), act_stride=n, sample_actions=sample_actions, obs=obs, reward=rew, terminated=term,
+                  truncated=trunc, out_stride=n, mix_a=mix.get("player_a"), mix_b=mix.get("player_b"), final_obs=fin, prob_code=code)
+        O, R8 = obs.download(), rew.download()
         TE, TR = term.download().view(np.bool_), trunc.download().view(np.bool_)
-        infos = {"_final_observation": TE[-1] | TR[-1], "reward_int8": R.astype(np.int8)}
-        if not sample_actions:
-            c = code.download(); f = fin.download()
-            lazy = _LazyInfo(lambda: self._p_rounded[c])
-            infos.update({ag: lazy for ag in ags}); infos["final_observation"] = {ag: f for ag in ags}
+        c, f = code.download(), fin.download()
+        lazy = _LazyInfo(lambda: self._p_rounded[c])
+        infos = {"_final_observation": TE | TR, "reward_int8": R8, "final_observation": {ag: f for ag in ags}}
+        infos.update({ag: lazy for ag in ags})
         for x in list(dev.values()) + [obs, rew, term, trunc, fin, code] + list(mix.values()):
             x.free()
         if self.strict:
             self._raise_on_misuse()
-        return ({ag: O for ag in ags}, self._rewards(R), {ag: TE for ag in ags}, {ag: TR for ag in ags}, infos)
+        return ({ag: O for ag in ags}, self._rewards(R8.astype(np.float32)), {ag: TE for ag in ags}, {ag: TR for ag in ags}, infos)
 
     def _mix_tables(self, mixed_policies, put):
         out = {}
@@ -358,19 +358,6 @@ class VectorSoccerEnv:
             assert ag in AGENTS, "mixed_policies keys are 'player_a' / 'player_b'"
             out[ag] = put(SoccerBatch.mixed_policy_thresholds(probs))
         return out
-
-    def _rollout_launch(self, T, a, bb, sample, mix, obs, rew, term, trunc, fin, code, finished, row):
-        """the launches of one rollout; `row(buffer, k)` = device address of row k of a [T, n] buffer"""
-        b, n = self._batch, self.num_envs
-        if sample:
-            b.rollout(T, sample_actions=True, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
-                      mix_a=mix.get("player_a"), mix_b=mix.get("player_b"))
-            return
-        if T > 1:
-            b.rollout(T - 1, a, bb, act_stride=n, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n)
-        k = T - 1
-        b.step(row(a, k), row(bb, k), obs=row(obs, k), reward=row(rew, k), terminated=row(term, k), truncated=row(trunc, k),
-               prob_code=code, final_obs=fin, finished=finished)
 
     def _rollout_device(self, T, a, bb, sample, mixed_policies):
         t, n, d, b = self._torch, self.num_envs, self._dev, self._batch
@@ -382,58 +369,52 @@ class VectorSoccerEnv:
         plan = getattr(self, "_roll_plan", None)
         if plan is None or plan["T"] != T:
             plan = self._roll_plan = self._make_roll_plan(T)      # one set of buffers: a new length replaces the old one
-        obs, rew, term, trunc = plan["bufs"]
         for lz in plan["lazy"]:                       # what the caller looked at after the previous rollout
             lz.invalidate()
-        if sample:
-            mix = self._mix_tables(mixed_policies, lambda tab: t.from_numpy(tab.view(np.int16)).to(d))
-            b.rollout(T, sample_actions=True, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
-                      mix_a=mix.get("player_a"), mix_b=mix.get("player_b"))
-            return plan["ret_sampled"]
-        # T - 1 fused steps, then the last one as a full step: two ctypes calls on argument blocks built once
-        pa = a.data_ptr() if a is not None else None
-        pb = bb.data_ptr() if bb is not None else None
-        if T > 1:
-            ra = plan["rollout_args"]; ra.act_a = pa; ra.act_b = pb
-            code = plan["rollout_call"](b.h, plan["rollout_ref"])
-            if code:
-                b._check(code)
-        sa = plan["step_args"]; last = (T - 1) * n
-        sa.act_a = None if pa is None else pa + last
-        sa.act_b = None if pb is None else pb + last
-        code = plan["step_call"](b.h, plan["step_ref"])
+        ra = plan["rollout_args"]
+        ra.sample_actions = 1 if sample else 0
+        ra.act_a = a.data_ptr() if a is not None else None
+        ra.act_b = bb.data_ptr() if bb is not None else None
+        mix = self._mix_tables(mixed_policies, lambda tab: t.from_numpy(tab.view(np.int16)).to(d)) if sample else {}
+        ra.mix_a = mix["player_a"].data_ptr() if "player_a" in mix else None
+        ra.mix_b = mix["player_b"].data_ptr() if "player_b" in mix else None
+        plan["mix_keep"] = mix                        # alive until the next rollout: the launch that reads them is asynchronous
+        code = plan["call"](b.h, plan["rollout_ref"], plan["extra_ref"])          # ONE ctypes call = one launch for the T steps
         if code:
             b._check(code)
         return plan["ret"]
 
     def _make_roll_plan(self, T):
         import ctypes
-        from .._lib import RolloutArgs, StepArgs
+        from .._lib import RolloutArgs, RolloutExtra
         t, n, d, b = self._torch, self.num_envs, self._dev, self._batch
         u16 = getattr(t, "uint16", t.int16)
         obs = t.empty((T, n), dtype=u16, device=d); rew = t.empty((T, n), dtype=t.int8, device=d)
         term = t.empty((T, n), dtype=t.uint8, device=d); trunc = t.empty((T, n), dtype=t.uint8, device=d)
-        fin = t.zeros(n, dtype=u16, device=d); code = t.zeros(n, dtype=t.uint8, device=d); finished = t.zeros(n, dtype=t.uint8, device=d)
         ags = self.return_agent
         term_b, trunc_b = term.view(t.bool), trunc.view(t.bool)
         thunks = {}
         if 'player_a' in ags: thunks['player_a'] = lambda: rew.to(t.float32)
         if 'player_b' in ags: thunks['player_b'] = lambda: 0.0 - rew.to(t.float32)          # :400-402, :243-244
         rewards = _Lazy(thunks)
-        p_lazy = _LazyInfo(lambda: self._prob[code.long()])
-        infos = {"reward_int8": rew, "final_observation": {ag: fin for ag in ags}, "_final_observation": finished.view(t.bool)}
-        infos.update({ag: p_lazy for ag in ags})
-        infos_sampled = _Lazy({"_final_observation": lambda: term_b[-1] | trunc_b[-1]}, {"reward_int8": rew})
-        O = {ag: obs for ag in ags}; TE = {ag: term_b for ag in ags}; TR = {ag: trunc_b for ag in ags}
-        last = T - 1
-        rollout_args = RolloutArgs(max(T - 1, 1), 0, None, None, n, obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), n,
+        lazies = [rewards]
+        eager = {"reward_int8": rew}
+        fin = code = None
+        if self.info:
+            fin = t.empty((T, n), dtype=u16, device=d); code = t.empty((T, n), dtype=t.uint8, device=d)
+            p_lazy = _LazyInfo(lambda: self._prob[code.long()])                             # np.round(prob, 2) of every sampled transition (:405)
+            lazies.append(p_lazy)
+            eager.update({ag: p_lazy for ag in ags})
+            eager["final_observation"] = {ag: fin for ag in ags}
+        infos = _Lazy({"_final_observation": lambda: term_b | trunc_b}, eager)
+        lazies.append(infos)
+        ret = ({ag: obs for ag in ags}, rewards, {ag: term_b for ag in ags}, {ag: trunc_b for ag in ags}, infos)
+        rollout_args = RolloutArgs(T, 0, None, None, n, obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), n,
                                    None, None, None, None)
-        step_args = StepArgs(None, None, None, None, obs[last].data_ptr(), rew[last].data_ptr(), term[last].data_ptr(), trunc[last].data_ptr(),
-                             code.data_ptr(), fin.data_ptr(), None, None, None, finished.data_ptr())
-        return {"T": T, "bufs": (obs, rew, term, trunc), "keep": (fin, code, finished), "lazy": (rewards, p_lazy, infos_sampled),
-                "ret": (O, rewards, TE, TR, infos), "ret_sampled": (O, rewards, TE, TR, infos_sampled),
-                "rollout_args": rollout_args, "rollout_ref": ctypes.byref(rollout_args), "rollout_call": b.lib.batched_rollout,
-                "step_args": step_args, "step_ref": ctypes.byref(step_args), "step_call": b.lib.batched_step_ex}
+        extra = RolloutExtra(None if fin is None else fin.data_ptr(), None if code is None else code.data_ptr())
+        return {"T": T, "bufs": (obs, rew, term, trunc, fin, code), "lazy": tuple(lazies), "ret": ret,
+                "rollout_args": rollout_args, "rollout_ref": ctypes.byref(rollout_args), "extra": extra, "extra_ref": ctypes.byref(extra),
+                "call": b.lib.batched_rollout_ex}
 
     @property
     def reward_int8(self):

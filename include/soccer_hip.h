@@ -63,7 +63,7 @@ extern "C" {
 
 #define SOCCER_ABI_VERSION 3      /* 2: soccer_step_args grew reward_a_f32 / reward_b_f32 / finished
                                      3: the bits -> uniform convention above (half-step offset; eight ticks per block at slip_prob == 0)
-                                     (still 3: soccer_trajectory_returns and soccer_comm_* were ADDED, captured sequences may hold an odd
+                                     (still 3: soccer_trajectory_returns, soccer_comm_* and batched_rollout_ex were ADDED, captured sequences may hold an odd
                                      number of calls, and a caller's u >= 1 on a slip list follows the reference's comparison — nothing a
                                      round-3 caller relied on changed, and checkpoints record this number for the RNG convention alone) */
 
@@ -166,6 +166,13 @@ typedef struct soccer_rollout_args {
     const uint16_t* mix_b;
 } soccer_rollout_args;
 
+/* batched_rollout_ex: per-step trajectories beyond the four result streams — what gym's vector convention reports next to them
+ * every step.  [T][n] with the args' out_stride; NULL = skipped.  With both NULL (or extra == NULL) the call IS batched_rollout. */
+typedef struct soccer_rollout_extra {
+    uint16_t*      final_obs;   /* observation BEFORE any auto-reset of that step (== obs where none fired); goal tuples -> 0 (:493-494) */
+    uint8_t*       prob_code;   /* code of the sampled transition's probability, see soccer_prob_table (info['p'], :405) */
+} soccer_rollout_extra;
+
 /* ---- lifetime ------------------------------------------------------------------------- */
 int soccer_abi_version(void);
 int soccer_device_count(int* count);
@@ -190,6 +197,7 @@ int batched_step(soccer_handle* h, const int8_t* act_a, const int8_t* act_b,
                  uint8_t* prob_code);
 int batched_step_ex(soccer_handle* h, const soccer_step_args* args);
 int batched_rollout(soccer_handle* h, const soccer_rollout_args* args);
+int batched_rollout_ex(soccer_handle* h, const soccer_rollout_args* args, const soccer_rollout_extra* extra);
 
 /* Host-pointer variants for small batches and numpy callers (the single-env facade): identical
  * semantics, but every array pointer is HOST memory.  The call stages inputs through one pinned

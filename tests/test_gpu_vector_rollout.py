@@ -1,5 +1,5 @@
 """-m gpu: VectorSoccerEnv.rollout(T, ...) is DEFINED as T successive step() calls stacked over T (the per-step return tuple of
-gym_soccer/envs/soccer_simultaneous_env.py:397-408, vectorised): same ticks, same auto-reset convention, same last-step infos.
+gym_soccer/envs/soccer_simultaneous_env.py:397-408, vectorised): same ticks, same auto-reset convention, same infos at every step.
 Twin environments (same seed, same lanes) — one stepped T times, one rolled out — must agree in every value, in both io modes,
 with and without slip, in multi-agent and in single-agent (fixed-opponent) mode."""
 import numpy as np
@@ -44,18 +44,21 @@ def test_device_rollout_equals_T_step_calls_on_65536_lanes(slip, mode):
         assert set(O) == set(R) == set(TE) == set(TR) == set(ags)
         for ag in ags:
             assert O[ag].shape == (T, n) and R[ag].dtype == torch.float32 and TE[ag].dtype == torch.bool
+        for ag in ags:
+            assert I["final_observation"][ag].shape == (T, n) and I[ag]["p"].shape == (T, n) and I["_final_observation"].shape == (T, n)
         for k in range(T):
             o, r, te, tr, i = e2.step({ag: acts[ag][k] for ag in ags})
             for ag in ags:
                 assert torch.equal(O[ag][k], o[ag]), (part, k, ag)
                 assert torch.equal(R[ag][k], r[ag]), (part, k, ag)
                 assert torch.equal(TE[ag][k], te[ag]) and torch.equal(TR[ag][k], tr[ag]), (part, k, ag)
-        # the last step's infos, as after step()
-        for ag in ags:
-            assert torch.equal(I[ag]["p"], i[ag]["p"])
-            assert torch.equal(I["final_observation"][ag], i["final_observation"][ag])
-        assert torch.equal(I["_final_observation"], i["_final_observation"])
-        assert torch.equal(I["reward_int8"][-1], e2.reward_int8)
+                # every step's infos, as after that step()
+                assert torch.equal(I[ag]["p"][k], i[ag]["p"]), (part, k, ag)
+                assert torch.equal(I["final_observation"][ag][k], i["final_observation"][ag]), (part, k, ag)
+            assert torch.equal(I["_final_observation"][k], i["_final_observation"]), (part, k)
+            assert torch.equal(I["reward_int8"][k], e2.reward_int8)
+        fin_k = I["final_observation"][ags[0]]
+        assert bool((fin_k != O[ags[0]]).any()), "no step reported a final observation that differs from the post-reset one"
         assert bool(TR[ags[0]].any()) and bool(TE[ags[0]].any())
     s1, s2 = e1.get_state(), e2.get_state()
     for key in s1:
@@ -80,11 +83,14 @@ def test_numpy_rollout_equals_T_step_calls(slip, mode):
         for ag in ags:
             np.testing.assert_array_equal(O[ag][k], o[ag]); np.testing.assert_array_equal(R[ag][k], r[ag])
             np.testing.assert_array_equal(TE[ag][k], te[ag]); np.testing.assert_array_equal(TR[ag][k], tr[ag])
+            np.testing.assert_array_equal(I[ag]["p"][k], i[ag]["p"]); np.testing.assert_array_equal(I["final_observation"][ag][k], i["final_observation"][ag])
+        np.testing.assert_array_equal(I["_final_observation"][k], i["_final_observation"])
     for ag in ags:
         assert R[ag].dtype == np.float32 and TE[ag].dtype == np.bool_
-        np.testing.assert_array_equal(I[ag]["p"], i[ag]["p"])
-        np.testing.assert_array_equal(I["final_observation"][ag], i["final_observation"][ag])
-    np.testing.assert_array_equal(I["_final_observation"], i["_final_observation"])
+        np.testing.assert_array_equal(I[ag]["p"][-1], i[ag]["p"])
+        np.testing.assert_array_equal(I["final_observation"][ag][-1], i["final_observation"][ag])
+    np.testing.assert_array_equal(I["_final_observation"][-1], i["_final_observation"])
+    assert I["final_observation"][ags[0]].shape == (T, n) and I["_final_observation"].shape == (T, n)
     s1, s2 = e1.get_state(), e2.get_state()
     for key in s1:
         np.testing.assert_array_equal(s1[key], s2[key])
@@ -100,7 +106,7 @@ def test_one_step_rollout_and_argument_checks():
     O, R, TE, TR, I = e1.rollout(1, {"player_a": a[:, 0], "player_b": a[:, 1]})
     o, r, te, tr, i = e2.step({"player_a": a[0, 0], "player_b": a[0, 1]})
     np.testing.assert_array_equal(O["player_a"][0], o["player_a"]); np.testing.assert_array_equal(R["player_b"][0], r["player_b"])
-    np.testing.assert_array_equal(I["player_a"]["p"], i["player_a"]["p"])
+    np.testing.assert_array_equal(I["player_a"]["p"][0], i["player_a"]["p"])
     with pytest.raises(AssertionError, match="0..4"):
         e1.rollout(2, {"player_a": np.full((2, 1024), 5), "player_b": np.zeros((2, 1024), int)})
     with pytest.raises(AssertionError, match="both 'player_a' and 'player_b'|length 2"):
@@ -133,7 +139,28 @@ def test_sampled_rollout_is_batched_rollout_with_in_kernel_actions(mixed):
     np.testing.assert_array_equal(_np(R["player_b"]), -rew.download().astype(np.float32))
     np.testing.assert_array_equal(_np(TE["player_a"]), term.download().view(np.bool_))
     np.testing.assert_array_equal(_np(TR["player_b"]), trunc.download().view(np.bool_))
-    np.testing.assert_array_equal(_np(I["_final_observation"]), (term.download()[-1] | trunc.download()[-1]).view(np.bool_))
+    np.testing.assert_array_equal(_np(I["_final_observation"]), (term.download() | trunc.download()).view(np.bool_))
+    # the sampled rollout reports every step's final observation too: where nothing ended it is the observation itself
+    fin = _np(I["final_observation"]["player_a"]).view(np.uint16); same = ~(term.download() | trunc.download()).view(np.bool_)
+    np.testing.assert_array_equal(fin[same], obs.download()[same])
+    assert (fin[~same] != obs.download()[~same]).any()
     np.testing.assert_array_equal(env.episode_histogram(), b.stats()[0])
     assert int(_np(TE["player_a"]).sum()) > 0
     env.close(); b.close()
+
+
+def test_lean_env_rollout_writes_no_info_trajectories():
+    import torch
+    n, T = 4096, 20
+    e1 = VectorSoccerEnv(n, slip_prob=0.2, seed=3, io="device", info=False)
+    e2 = VectorSoccerEnv(n, slip_prob=0.2, seed=3, io="device", info=False)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    acts = {ag: torch.randint(0, 5, (T, n), dtype=torch.int8, device="cuda", generator=g) for ag in ("player_a", "player_b")}
+    O, R, TE, TR, I = e1.rollout(T, acts)
+    assert "final_observation" not in I and "player_a" not in I and I["_final_observation"].shape == (T, n)
+    for k in range(T):
+        o, r, te, tr, i = e2.step({ag: acts[ag][k] for ag in acts})
+        assert torch.equal(O["player_a"][k], o["player_a"]) and torch.equal(R["player_b"][k], r["player_b"])
+        assert torch.equal(I["_final_observation"][k], i["_final_observation"])
+    e1.close(); e2.close()

@@ -91,6 +91,10 @@ while time.time() - t0 < budget:
         T = int(rng.integers(1, 50)); mode = rng.integers(0, 4)
         O = b.alloc((T, n), np.uint16); R = b.alloc((T, n), np.int8); TE = b.alloc((T, n), np.uint8); TR = b.alloc((T, n), np.uint8)
         kw = dict(obs=O, reward=R, terminated=TE, truncated=TR, out_stride=n)
+        # batched_rollout_ex: the per-step final observation / probability code, each asked for independently
+        FO = b.alloc((T, n), np.uint16) if rng.random() < 0.5 else None
+        CD = b.alloc((T, n), np.uint8) if rng.random() < 0.5 else None
+        kw.update(final_obs=FO, prob_code=CD)
         acts = rng.integers(0, 5, size=(T, 2, n), dtype=np.int8)
         mix = None; pol = None
         if mode == 0:
@@ -108,6 +112,7 @@ while time.time() - t0 < budget:
             A = b.alloc((T, n), np.int8).upload(acts[:, 0])
             b.rollout(T, A, None, act_stride=n, **kw)
         Oh, Rh, TEh, TRh = O.download(), R.download(), TE.download(), TR.download()
+        FOh = None if FO is None else FO.download(); CDh = None if CD is None else CD.download()
         for k in range(T):
             if mode == 0: a, bb = acts[k, 0], acts[k, 1]
             elif mode == 1: a, bb = o.sample_actions_mixed(cur)
@@ -116,6 +121,8 @@ while time.time() - t0 < budget:
             c = o.step(a, bb)
             assert np.array_equal(Oh[k], c["obs"]) and np.array_equal(Rh[k], c["reward"]), "rollout mode %d step %d %s" % (mode, k, tag)
             assert np.array_equal(TEh[k], c["terminated"]) and np.array_equal(TRh[k], c["truncated"]), "rollout flags " + tag
+            assert FOh is None or np.array_equal(FOh[k], c["final_obs"]), "rollout final_obs mode %d step %d %s" % (mode, k, tag)
+            assert CDh is None or np.array_equal(CDh[k], c["prob_code"]), "rollout prob_code mode %d step %d %s" % (mode, k, tag)
             cur = c["obs"]; lanes_steps += n
         s = b.get_state()
         for key, v in (("row_a", o.row_a), ("col_a", o.col_a), ("row_b", o.row_b), ("col_b", o.col_b), ("poss", o.poss & 1), ("needs_reset", (o.poss >> 1) & 1), ("t", o.t)):
