@@ -274,8 +274,9 @@ def vector_env_leg(args):
         out[key] = {"api": "VectorSoccerEnv(io='device', info=%s).step(dict of int8 CUDA tensors)" % info, "steps": KV,
                     "us_per_step": dv / KV * 1e6, "env_steps_per_s": N * KV / dv, "bytes_per_env_step": nbytes, "note": note}
         if key == "full" and args.rollout > 0:
-            # the fused path behind the same API: rollout(T) == T step() calls (tests/test_gpu_vector_rollout.py), T - 1 of them in one
-            # launch with the state in registers; [T, N] trajectories of obs / int8 reward / terminated / truncated + last-step infos
+            # the fused path behind the same API: rollout(T) == T step() calls (tests/test_gpu_vector_rollout.py) with the state in
+            # registers: [T, N] trajectories of obs / int8 reward / terminated / truncated + the last step's infos (the default,
+            # infos="last": T - 1 fused steps + one full step), or every step's final_obs / prob_code as well (infos="all": one launch)
             T = args.rollout
             ra = {"player_a": acts[:T, 0].contiguous(), "player_b": acts[:T, 1].contiguous()}
             v.rollout(T, ra); torch.cuda.synchronize()
@@ -288,8 +289,16 @@ def vector_env_leg(args):
             out["rollout"] = {"api": "VectorSoccerEnv(io='device').rollout(T=%d, dict of [T, N] int8 CUDA tensors)" % T, "steps_fused": T,
                               "ms_per_rollout": dt * 1e3, "env_steps_per_s": N * T / dt, "bytes_per_env_step": bpe,
                               "frac_of_hbm_peak": bpe * N * T / dt / 1e9 / HBM_PEAK_GBPS,
-                              "note": "wall clock around the call + torch.cuda.synchronize(), median of 5; T - 1 steps by batched_rollout, the last by "
-                                      "batched_step_ex (last-step infos)"}
+                              "note": "wall clock around the call + torch.cuda.synchronize(), median of 5; infos='last' (the default): T - 1 steps by "
+                                      "batched_rollout, the last by batched_step_ex (the T-th step's infos)"}
+            for mode, key2, b2 in (("all", "rollout_infos_all", 10 + 12.0 / T), ("none", "rollout_infos_none", 7 + 12.0 / T)):
+                v.rollout(T, ra, infos=mode); torch.cuda.synchronize()
+                reps = []
+                for _ in range(5):
+                    t0 = time.perf_counter(); v.rollout(T, ra, infos=mode); torch.cuda.synchronize(); reps.append(time.perf_counter() - t0)
+                out[key2] = {"api": "VectorSoccerEnv(io='device').rollout(T=%d, ..., infos='%s')" % (T, mode), "steps_fused": T,
+                             "ms_per_rollout": sorted(reps)[2] * 1e3, "env_steps_per_s": N * T / sorted(reps)[2], "bytes_per_env_step": b2,
+                             "note": "one batched_rollout_ex launch; 'all' = + every step's final_observation and prob_code trajectories"}
         v.close()
     print(json.dumps(out))
 

@@ -295,27 +295,34 @@ class VectorSoccerEnv:
         return self._ret_obs, self._ret_rew, self._ret_term, self._ret_trunc, self._ret_infos
 
     # ---------------------------------------------------------------------------------------------
-    def rollout(self, n_steps, actions=None, sample_actions=False, mixed_policies=None):
-        """T = `n_steps` fused steps in ONE launch — by definition EXACTLY what T successive `step()` calls return, stacked over T
-        (same ticks, same auto-reset convention: soccer_simultaneous_env.py:397-408 per step), infos included: `batched_rollout_ex`
-        keeps the state in registers and writes every step's row of every stream.
+    def rollout(self, n_steps, actions=None, sample_actions=False, mixed_policies=None, infos="last"):
+        """T = `n_steps` fused steps — by definition EXACTLY what T successive `step()` calls return, stacked over T (same ticks,
+        same auto-reset convention: soccer_simultaneous_env.py:397-408 per step) — with the state in registers for the whole run.
 
         actions  dict like step()'s, every value [T, num_envs] (device io: contiguous torch.int8 CUDA tensors; numpy io: integer
                  arrays, checked to be 0..4 on the host).  Single-agent mode: the learner's key only.
         sample_actions=True (actions None)  both players act uniformly at random, drawn in the kernel from the lanes' purpose-1
                  Philox words (include/soccer_hip.h); `mixed_policies` = {agent: [nS, 5] probabilities} samples that agent's
                  action from its row of the current observation instead (BASELINE config 5).
+        infos    which of step()'s infos come back:
+                 "last" (default)  the LAST step's, exactly as after the T-th step() call — `batched_rollout` for T - 1 steps and
+                         one full `batched_step_ex` (7 B per env-step; with sampled actions all T steps are fused and only
+                         `_final_observation` of the last step is reported);
+                 "all"   every step's, stacked over T like everything else: infos["final_observation"][agent] [T, num_envs] (the
+                         observation before that step's auto-reset — what a learner bootstraps from at a truncation),
+                         infos["_final_observation"] [T, num_envs], infos[agent]["p"] [T, num_envs] — ONE `batched_rollout_ex`
+                         launch (10 B per env-step and a second observation index per step);
+                 "none"  neither (what an `info=False` env gives whatever is asked): `_final_observation` [T, num_envs] on access.
 
         Returns (observations, rewards, terminated, truncated, infos): dicts per returned agent of [T, num_envs] arrays —
         uint16 observations, float32 rewards (device io: cast from the kernel's int8 trajectory on first access; the int8
-        trajectory of player A's reward is infos["reward_int8"]), bool flags — and infos stacked the same way:
-        infos["final_observation"][agent] [T, num_envs] (the observation before that step's auto-reset: what a learner
-        bootstraps from at a truncation), infos["_final_observation"] (= terminated | truncated), infos[agent]["p"] (on first
-        access).  With info=False (device io) the two info trajectories are not written (7 instead of 10 B per env-step).
-        The arrays are buffers the env owns, one set per T, overwritten by the next rollout of the same length."""
+        trajectory of player A's reward is infos["reward_int8"]), bool flags.  The arrays are buffers the env owns, one set per
+        (T, infos), overwritten by the next such rollout."""
         assert not self._needs_reset, "Please reset the environment before taking a step"
+        assert infos in ("last", "all", "none"), "infos must be 'last', 'all' or 'none'"
         T, n, b = int(n_steps), self.num_envs, self._batch
         assert T >= 1, "n_steps must be >= 1"
+        mode = infos if self.info else "none"
         ags = self.return_agent
         if sample_actions:
             assert actions is None and self.multiagent, "sample_actions: no action streams, both players are sampled"
@@ -324,8 +331,8 @@ class VectorSoccerEnv:
             assert mixed_policies is None, "mixed_policies needs sample_actions=True"
             a, bb = self._check_actions(actions)
         if self.io == "device":
-            return self._rollout_device(T, a, bb, sample_actions, mixed_policies)
-        # ---- numpy io: host arrays in, host arrays out; the same launch, one upload and one download --------------------
+            return self._rollout_device(T, a, bb, sample_actions, mixed_policies, mode)
+        # ---- numpy io: host arrays in, host arrays out; the same launches, one upload and one download ------------------
         dev = {}
         for key, x in (("a", a), ("b", bb)):
             if x is None:
@@ -336,21 +343,43 @@ class VectorSoccerEnv:
             dev[key] = b.alloc((T, n), np.int8).upload(x.astype(np.int8, copy=False))
         obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8)
         term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
-        fin = b.alloc((T, n), np.uint16); code = b.alloc((T, n), np.uint8)
+        last_only = mode == "last" and not sample_actions
+        rows = 1 if last_only else T
+        fin = b.alloc((rows, n), np.uint16) if mode != "none" else None
+        code = b.alloc((rows, n), np.uint8) if mode != "none" else None
         mix = self._mix_tables(mixed_policies, lambda t: b.alloc(t.shape, np.uint16).upload(t)) if sample_actions else {}
-        b.rollout(T, dev.get("a"), dev.get("b"), act_stride=n, sample_actions=sample_actions, obs=obs, reward=rew, terminated=term,
-                  truncated=trunc, out_stride=n, mix_a=mix.get("player_a"), mix_b=mix.get("player_b"), final_obs=fin, prob_code=code)
+        kw = dict(obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n)
+        if last_only:
+            if T > 1:
+                b.rollout(T - 1, dev.get("a"), dev.get("b"), act_stride=n, **kw)
+            k = T - 1
+            row = lambda arr: None if arr is None else arr.row(k)
+            b.step(row(dev.get("a")), row(dev.get("b")), obs=obs.row(k), reward=rew.row(k), terminated=term.row(k), truncated=trunc.row(k),
+                   prob_code=code, final_obs=fin)
+        else:
+            full = mode == "all"
+            b.rollout(T, dev.get("a"), dev.get("b"), act_stride=n, sample_actions=sample_actions, mix_a=mix.get("player_a"),
+                      mix_b=mix.get("player_b"), final_obs=fin if full else None, prob_code=code if full else None, **kw)
         O, R8 = obs.download(), rew.download()
         TE, TR = term.download().view(np.bool_), trunc.download().view(np.bool_)
-        c, f = code.download(), fin.download()
-        lazy = _LazyInfo(lambda: self._p_rounded[c])
-        infos = {"_final_observation": TE | TR, "reward_int8": R8, "final_observation": {ag: f for ag in ags}}
-        infos.update({ag: lazy for ag in ags})
-        for x in list(dev.values()) + [obs, rew, term, trunc, fin, code] + list(mix.values()):
+        out_infos = {"reward_int8": R8}
+        if mode == "all":
+            c, f = code.download(), fin.download()
+            lazy = _LazyInfo(lambda: self._p_rounded[c])
+            out_infos.update({ag: lazy for ag in ags}); out_infos["final_observation"] = {ag: f for ag in ags}
+            out_infos["_final_observation"] = TE | TR
+        elif last_only:
+            c, f = code.download()[0], fin.download()[0]
+            lazy = _LazyInfo(lambda: self._p_rounded[c])
+            out_infos.update({ag: lazy for ag in ags}); out_infos["final_observation"] = {ag: f for ag in ags}
+            out_infos["_final_observation"] = TE[-1] | TR[-1]
+        else:
+            out_infos["_final_observation"] = (TE[-1] | TR[-1]) if mode == "last" else (TE | TR)
+        for x in list(dev.values()) + [obs, rew, term, trunc] + [y for y in (fin, code) if y is not None] + list(mix.values()):
             x.free()
         if self.strict:
             self._raise_on_misuse()
-        return ({ag: O for ag in ags}, self._rewards(R8.astype(np.float32)), {ag: TE for ag in ags}, {ag: TR for ag in ags}, infos)
+        return ({ag: O for ag in ags}, self._rewards(R8.astype(np.float32)), {ag: TE for ag in ags}, {ag: TR for ag in ags}, out_infos)
 
     def _mix_tables(self, mixed_policies, put):
         out = {}
@@ -359,34 +388,47 @@ class VectorSoccerEnv:
             out[ag] = put(SoccerBatch.mixed_policy_thresholds(probs))
         return out
 
-    def _rollout_device(self, T, a, bb, sample, mixed_policies):
+    def _rollout_device(self, T, a, bb, sample, mixed_policies, mode):
         t, n, d, b = self._torch, self.num_envs, self._dev, self._batch
         for x in (a, bb):
             assert x is None or (x.dtype is t.int8 and x.is_cuda and x.shape == (T, n) and x.is_contiguous()), \
                 "device io expects contiguous torch.int8 CUDA tensors of shape [n_steps, num_envs]"
         if self.strict and b.peek_misuse():           # (like step(): what the launches completed so far have raised)
             self._raise_on_misuse()
+        key = (T, mode, bool(sample))
         plan = getattr(self, "_roll_plan", None)
-        if plan is None or plan["T"] != T:
-            plan = self._roll_plan = self._make_roll_plan(T)      # one set of buffers: a new length replaces the old one
+        if plan is None or plan["key"] != key:
+            plan = self._roll_plan = self._make_roll_plan(T, mode, bool(sample))     # one set of buffers: another shape replaces it
         for lz in plan["lazy"]:                       # what the caller looked at after the previous rollout
             lz.invalidate()
         ra = plan["rollout_args"]
-        ra.sample_actions = 1 if sample else 0
-        ra.act_a = a.data_ptr() if a is not None else None
-        ra.act_b = bb.data_ptr() if bb is not None else None
-        mix = self._mix_tables(mixed_policies, lambda tab: t.from_numpy(tab.view(np.int16)).to(d)) if sample else {}
-        ra.mix_a = mix["player_a"].data_ptr() if "player_a" in mix else None
-        ra.mix_b = mix["player_b"].data_ptr() if "player_b" in mix else None
-        plan["mix_keep"] = mix                        # alive until the next rollout: the launch that reads them is asynchronous
-        code = plan["call"](b.h, plan["rollout_ref"], plan["extra_ref"])          # ONE ctypes call = one launch for the T steps
+        pa = a.data_ptr() if a is not None else None
+        pb = bb.data_ptr() if bb is not None else None
+        ra.act_a = pa; ra.act_b = pb
+        if sample:
+            mix = self._mix_tables(mixed_policies, lambda tab: t.from_numpy(tab.view(np.int16)).to(d))
+            ra.mix_a = mix["player_a"].data_ptr() if "player_a" in mix else None
+            ra.mix_b = mix["player_b"].data_ptr() if "player_b" in mix else None
+            plan["mix_keep"] = mix                    # alive until the next rollout: the launch that reads them is asynchronous
+        if plan["last_only"]:
+            # T - 1 fused steps, then the last one as a full step: two ctypes calls on argument blocks built once
+            if T > 1:
+                code = plan["rollout_call"](b.h, plan["rollout_ref"])
+                if code:
+                    b._check(code)
+            sa = plan["step_args"]; last = (T - 1) * n
+            sa.act_a = None if pa is None else pa + last
+            sa.act_b = None if pb is None else pb + last
+            code = plan["step_call"](b.h, plan["step_ref"])
+        else:
+            code = plan["rollout_ex_call"](b.h, plan["rollout_ref"], plan["extra_ref"])     # ONE ctypes call = one launch for the T steps
         if code:
             b._check(code)
         return plan["ret"]
 
-    def _make_roll_plan(self, T):
+    def _make_roll_plan(self, T, mode, sample):
         import ctypes
-        from .._lib import RolloutArgs, RolloutExtra
+        from .._lib import RolloutArgs, RolloutExtra, StepArgs
         t, n, d, b = self._torch, self.num_envs, self._dev, self._batch
         u16 = getattr(t, "uint16", t.int16)
         obs = t.empty((T, n), dtype=u16, device=d); rew = t.empty((T, n), dtype=t.int8, device=d)
@@ -399,22 +441,36 @@ class VectorSoccerEnv:
         rewards = _Lazy(thunks)
         lazies = [rewards]
         eager = {"reward_int8": rew}
-        fin = code = None
-        if self.info:
-            fin = t.empty((T, n), dtype=u16, device=d); code = t.empty((T, n), dtype=t.uint8, device=d)
-            p_lazy = _LazyInfo(lambda: self._prob[code.long()])                             # np.round(prob, 2) of every sampled transition (:405)
+        last_only = mode == "last" and not sample
+        fin = code = finished = None
+        if mode == "all" or last_only:
+            shape = (n,) if last_only else (T, n)
+            fin = t.empty(shape, dtype=u16, device=d); code = t.empty(shape, dtype=t.uint8, device=d)
+            p_lazy = _LazyInfo(lambda: self._prob[code.long()])                             # np.round(prob, 2) of the sampled transition(s) (:405)
             lazies.append(p_lazy)
             eager.update({ag: p_lazy for ag in ags})
             eager["final_observation"] = {ag: fin for ag in ags}
-        infos = _Lazy({"_final_observation": lambda: term_b | trunc_b}, eager)
-        lazies.append(infos)
+        if last_only:
+            finished = t.empty(n, dtype=t.uint8, device=d)
+            eager["_final_observation"] = finished.view(t.bool)
+            infos = eager
+        else:
+            infos = _Lazy({"_final_observation": (lambda: term_b[-1] | trunc_b[-1]) if mode == "last" else (lambda: term_b | trunc_b)}, eager)
+            lazies.append(infos)
         ret = ({ag: obs for ag in ags}, rewards, {ag: term_b for ag in ags}, {ag: trunc_b for ag in ags}, infos)
-        rollout_args = RolloutArgs(T, 0, None, None, n, obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), n,
-                                   None, None, None, None)
-        extra = RolloutExtra(None if fin is None else fin.data_ptr(), None if code is None else code.data_ptr())
-        return {"T": T, "bufs": (obs, rew, term, trunc, fin, code), "lazy": tuple(lazies), "ret": ret,
-                "rollout_args": rollout_args, "rollout_ref": ctypes.byref(rollout_args), "extra": extra, "extra_ref": ctypes.byref(extra),
-                "call": b.lib.batched_rollout_ex}
+        rollout_args = RolloutArgs(max(T - 1, 1) if last_only else T, 1 if sample else 0, None, None, n, obs.data_ptr(), rew.data_ptr(),
+                                   term.data_ptr(), trunc.data_ptr(), n, None, None, None, None)
+        full = mode == "all"
+        extra = RolloutExtra(fin.data_ptr() if full else None, code.data_ptr() if full else None)
+        plan = {"key": (T, mode, sample), "bufs": (obs, rew, term, trunc, fin, code, finished), "lazy": tuple(lazies), "ret": ret,
+                "last_only": last_only, "rollout_args": rollout_args, "rollout_ref": ctypes.byref(rollout_args), "extra": extra,
+                "extra_ref": ctypes.byref(extra), "rollout_call": b.lib.batched_rollout, "rollout_ex_call": b.lib.batched_rollout_ex}
+        if last_only:
+            k = T - 1
+            step_args = StepArgs(None, None, None, None, obs[k].data_ptr(), rew[k].data_ptr(), term[k].data_ptr(), trunc[k].data_ptr(),
+                                 code.data_ptr(), fin.data_ptr(), None, None, None, finished.data_ptr())
+            plan.update(step_args=step_args, step_ref=ctypes.byref(step_args), step_call=b.lib.batched_step_ex)
+        return plan
 
     @property
     def reward_int8(self):

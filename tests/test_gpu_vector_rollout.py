@@ -28,9 +28,10 @@ def _twins(n, slip, mode, io, **kw):
     return mk(), mk()
 
 
+@pytest.mark.parametrize("infos", ["last", "all"])
 @pytest.mark.parametrize("slip", [0.0, 0.2])
 @pytest.mark.parametrize("mode", ["multiagent", "learner_a", "learner_b"])
-def test_device_rollout_equals_T_step_calls_on_65536_lanes(slip, mode):
+def test_device_rollout_equals_T_step_calls_on_65536_lanes(slip, mode, infos):
     import torch
     n, T = 65536, 130                      # > 100 steps: every lane truncates at least once, goals auto-reset in between
     e1, e2 = _twins(n, slip, mode, "device")
@@ -40,25 +41,32 @@ def test_device_rollout_equals_T_step_calls_on_65536_lanes(slip, mode):
     acts = {ag: torch.randint(0, 5, (T, n), dtype=torch.int8, device="cuda", generator=g) for ag in ags}
     # two rollouts back to back (the second starts mid-episode and re-uses the buffers), against 2 T single steps
     for part in range(2):
-        O, R, TE, TR, I = e1.rollout(T, acts)
+        O, R, TE, TR, I = e1.rollout(T, acts, infos=infos)
         assert set(O) == set(R) == set(TE) == set(TR) == set(ags)
+        every = infos == "all"
+        shape = (T, n) if every else (n,)
         for ag in ags:
             assert O[ag].shape == (T, n) and R[ag].dtype == torch.float32 and TE[ag].dtype == torch.bool
-        for ag in ags:
-            assert I["final_observation"][ag].shape == (T, n) and I[ag]["p"].shape == (T, n) and I["_final_observation"].shape == (T, n)
+            assert I["final_observation"][ag].shape == shape and I[ag]["p"].shape == shape and I["_final_observation"].shape == shape
         for k in range(T):
             o, r, te, tr, i = e2.step({ag: acts[ag][k] for ag in ags})
             for ag in ags:
                 assert torch.equal(O[ag][k], o[ag]), (part, k, ag)
                 assert torch.equal(R[ag][k], r[ag]), (part, k, ag)
                 assert torch.equal(TE[ag][k], te[ag]) and torch.equal(TR[ag][k], tr[ag]), (part, k, ag)
-                # every step's infos, as after that step()
-                assert torch.equal(I[ag]["p"][k], i[ag]["p"]), (part, k, ag)
-                assert torch.equal(I["final_observation"][ag][k], i["final_observation"][ag]), (part, k, ag)
-            assert torch.equal(I["_final_observation"][k], i["_final_observation"]), (part, k)
+                if every:                       # every step's infos, as after that step()
+                    assert torch.equal(I[ag]["p"][k], i[ag]["p"]), (part, k, ag)
+                    assert torch.equal(I["final_observation"][ag][k], i["final_observation"][ag]), (part, k, ag)
+            if every:
+                assert torch.equal(I["_final_observation"][k], i["_final_observation"]), (part, k)
             assert torch.equal(I["reward_int8"][k], e2.reward_int8)
-        fin_k = I["final_observation"][ags[0]]
-        assert bool((fin_k != O[ags[0]]).any()), "no step reported a final observation that differs from the post-reset one"
+        if every:
+            fin_k = I["final_observation"][ags[0]]
+            assert bool((fin_k != O[ags[0]]).any()), "no step reported a final observation that differs from the post-reset one"
+        else:                                   # the last step's infos, as after the T-th step()
+            for ag in ags:
+                assert torch.equal(I[ag]["p"], i[ag]["p"]) and torch.equal(I["final_observation"][ag], i["final_observation"][ag])
+            assert torch.equal(I["_final_observation"], i["_final_observation"])
         assert bool(TR[ags[0]].any()) and bool(TE[ags[0]].any())
     s1, s2 = e1.get_state(), e2.get_state()
     for key in s1:
@@ -77,7 +85,7 @@ def test_numpy_rollout_equals_T_step_calls(slip, mode):
     ags = e1.return_agent
     rng = np.random.default_rng(8)
     acts = {ag: rng.integers(0, 5, size=(T, n)) for ag in ags}
-    O, R, TE, TR, I = e1.rollout(T, acts)
+    O, R, TE, TR, I = e1.rollout(T, acts, infos="all")
     for k in range(T):
         o, r, te, tr, i = e2.step({ag: acts[ag][k] for ag in ags})
         for ag in ags:
@@ -103,10 +111,14 @@ def test_one_step_rollout_and_argument_checks():
         e1.rollout(3, {"player_a": np.zeros((3, 1024), int), "player_b": np.zeros((3, 1024), int)})
     e1.reset(); e2.reset()
     a = np.random.default_rng(1).integers(0, 5, size=(1, 2, 1024))
-    O, R, TE, TR, I = e1.rollout(1, {"player_a": a[:, 0], "player_b": a[:, 1]})
+    O, R, TE, TR, I = e1.rollout(1, {"player_a": a[:, 0], "player_b": a[:, 1]})          # infos="last": the default
     o, r, te, tr, i = e2.step({"player_a": a[0, 0], "player_b": a[0, 1]})
     np.testing.assert_array_equal(O["player_a"][0], o["player_a"]); np.testing.assert_array_equal(R["player_b"][0], r["player_b"])
-    np.testing.assert_array_equal(I["player_a"]["p"][0], i["player_a"]["p"])
+    np.testing.assert_array_equal(I["player_a"]["p"], i["player_a"]["p"])
+    np.testing.assert_array_equal(I["final_observation"]["player_b"], i["final_observation"]["player_b"])
+    np.testing.assert_array_equal(I["_final_observation"], i["_final_observation"])
+    with pytest.raises(AssertionError, match="'last', 'all' or 'none'"):
+        e1.rollout(2, {"player_a": np.zeros((2, 1024), int), "player_b": np.zeros((2, 1024), int)}, infos="some")
     with pytest.raises(AssertionError, match="0..4"):
         e1.rollout(2, {"player_a": np.full((2, 1024), 5), "player_b": np.zeros((2, 1024), int)})
     with pytest.raises(AssertionError, match="both 'player_a' and 'player_b'|length 2"):
@@ -131,7 +143,7 @@ def test_sampled_rollout_is_batched_rollout_with_in_kernel_actions(mixed):
         mp = {"player_a": rng.dirichlet(np.ones(5) * 0.7, size=env.nS), "player_b": rng.dirichlet(np.ones(5) * 0.7, size=env.nS)}
         kw = {"mix_a": b.alloc((env.nS, 4), np.uint16).upload(SoccerBatch.mixed_policy_thresholds(mp["player_a"])),
               "mix_b": b.alloc((env.nS, 4), np.uint16).upload(SoccerBatch.mixed_policy_thresholds(mp["player_b"]))}
-    O, R, TE, TR, I = env.rollout(T, sample_actions=True, mixed_policies=mp)
+    O, R, TE, TR, I = env.rollout(T, sample_actions=True, mixed_policies=mp, infos="all")
     obs = b.alloc((T, n), np.uint16); rew = b.alloc((T, n), np.int8); term = b.alloc((T, n), np.uint8); trunc = b.alloc((T, n), np.uint8)
     b.rollout(T, sample_actions=True, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n, **kw)
     np.testing.assert_array_equal(_np(O["player_a"]).view(np.uint16), obs.download())
@@ -157,7 +169,7 @@ def test_lean_env_rollout_writes_no_info_trajectories():
     e1.reset(); e2.reset()
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     acts = {ag: torch.randint(0, 5, (T, n), dtype=torch.int8, device="cuda", generator=g) for ag in ("player_a", "player_b")}
-    O, R, TE, TR, I = e1.rollout(T, acts)
+    O, R, TE, TR, I = e1.rollout(T, acts, infos="all")                  # an info=False env has none to give: "none" whatever is asked
     assert "final_observation" not in I and "player_a" not in I and I["_final_observation"].shape == (T, n)
     for k in range(T):
         o, r, te, tr, i = e2.step({ag: acts[ag][k] for ag in acts})
