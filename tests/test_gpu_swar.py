@@ -117,7 +117,14 @@ def test_step_kernel_swar_fixed_policy(w, h, slip, fixed, full):
     b.close()
 
 
-def _rollout_vs_oracle(b, o, acts, T, n, sample=False, mix=None):
+_EXTRAS = [0]
+
+
+def _rollout_vs_oracle(b, o, acts, T, n, sample=False, mix=None, extras=None):
+    """extras: also ask for batched_rollout_ex's per-step final_obs / prob_code and check them; None = every other call of this
+    helper, so that both the plain and the FULL instantiations see every parametrisation family"""
+    if extras is None:
+        _EXTRAS[0] += 1; extras = bool(_EXTRAS[0] & 1)
     A = B = None
     if not sample:
         A = b.alloc((T, n), np.int8).upload(acts[:, 0]); B = b.alloc((T, n), np.int8).upload(acts[:, 1])
@@ -129,9 +136,11 @@ def _rollout_vs_oracle(b, o, acts, T, n, sample=False, mix=None):
     da = db = None
     if mix is not None:
         da = b.alloc(mix[0].shape, np.uint16).upload(mix[0]); db = b.alloc(mix[1].shape, np.uint16).upload(mix[1])
+    fo = b.alloc((T, n), np.uint16).fill(0xEE) if extras else None; cd = b.alloc((T, n), np.uint8).fill(0xEE) if extras else None
     b.rollout(T, A, B, act_stride=n, sample_actions=sample, obs=obs, reward=rew, terminated=term, truncated=trunc, out_stride=n,
-              return_sum=rs, episode_count=ec, mix_a=da, mix_b=db)
+              return_sum=rs, episode_count=ec, mix_a=da, mix_b=db, final_obs=fo, prob_code=cd)
     O, R, TE, TR = obs.download(), rew.download(), term.download(), trunc.download()
+    FO = fo.download() if extras else None; CD = cd.download() if extras else None
     ret = np.zeros(n, np.int64); eps = np.zeros(n, np.int64)
     for k in range(T):
         if sample:
@@ -141,6 +150,9 @@ def _rollout_vs_oracle(b, o, acts, T, n, sample=False, mix=None):
         c = o.step(a, bb)
         np.testing.assert_array_equal(O[k], c["obs"], err_msg="obs %d" % k); np.testing.assert_array_equal(R[k], c["reward"], err_msg="reward %d" % k)
         np.testing.assert_array_equal(TE[k], c["terminated"]); np.testing.assert_array_equal(TR[k], c["truncated"])
+        if extras:
+            np.testing.assert_array_equal(FO[k], c["final_obs"], err_msg="final_obs %d" % k)
+            np.testing.assert_array_equal(CD[k], c["prob_code"], err_msg="prob_code %d" % k)
         frozen = ((o.poss >> 1) & 1).astype(bool) if not o.autoreset else np.zeros(n, bool)
         ret += c["reward"]; eps += ((c["terminated"] | c["truncated"]) != 0)
         cur = c["obs"]

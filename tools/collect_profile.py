@@ -237,10 +237,12 @@ def report(tag):
             if "rollout_swar_kernel<0," in k:                                 # action streams in, four trajectories out, state once
                 bl = _line(tag, {"kernel_stats_full": "bench_full", "kernel_stats_slip0p2": "bench_slip_unprofiled", "kernel_stats_venv": "venv_profiled"}.get(name, ""))
                 T = (bl.get("fused_rollout") or bl.get("rollout") or {}).get("steps_fused") if bl else None
-                if T and name == "kernel_stats_venv":
-                    T -= 1                                                    # VectorSoccerEnv.rollout: T - 1 fused steps + one full step
+                full = k.endswith(", true>")                                  # batched_rollout_ex: + final_obs (2 B) and prob_code (1 B) per step
+                if T and name == "kernel_stats_venv" and not full:
+                    T -= 1                                                    # rollout(infos="last"): T - 1 fused steps + one full step (infos="none": T)
                 if T:
-                    nb, what = (7 * T + 12) * N, "7 B/lane-step x %d + 12 B/lane" % T
+                    per = 10 if full else 7
+                    nb, what = (per * T + 12) * N, "%d B/lane-step x %d + 12 B/lane" % (per, T)
             if "trajectory_returns_kernel" in k:                      # its T is the pass's: the bench line's K, or profile_others.py's 64
                 bl = _line(tag, {"kernel_stats": "bench", "kernel_stats_full": "bench_full", "kernel_stats_slip0p2": "bench_slip_unprofiled"}.get(name, ""))
                 T = bl["steps"] if bl else (64 if name == "kernel_stats_other" else None)
