@@ -44,6 +44,7 @@ int main(void) {
            offsetof(soccer_rollout_args, mix_a));
     printf("%zu %zu %zu %zu %zu\\n", sizeof(soccer_scalar_io), offsetof(soccer_scalar_io, act_a), offsetof(soccer_scalar_io, obs),
            offsetof(soccer_scalar_io, u_step), offsetof(soccer_scalar_io, u_reset));
+    printf("%zu %zu %d\\n", sizeof(soccer_rollout_extra), offsetof(soccer_rollout_extra, prob_code), SOCCER_COMM_ID_BYTES);
     return 0;
 }
 """)
@@ -55,7 +56,8 @@ int main(void) {
     assert got == [C.sizeof(Cfg), C.sizeof(St), C.sizeof(Ro),
                    Cfg.slip_prob.offset, Cfg.seed.offset, Cfg.flags.offset, Cfg.stream.offset,
                    Ro.act_stride.offset, Ro.out_stride.offset, Ro.mix_a.offset,
-                   C.sizeof(Sc), Sc.act_a.offset, Sc.obs.offset, Sc.u_step.offset, Sc.u_reset.offset]
+                   C.sizeof(Sc), Sc.act_a.offset, Sc.obs.offset, Sc.u_step.offset, Sc.u_reset.offset,
+                   C.sizeof(_lib.RolloutExtra), _lib.RolloutExtra.prob_code.offset, _lib.COMM_ID_BYTES]
 
 
 def test_flag_and_error_constants_match_header():
