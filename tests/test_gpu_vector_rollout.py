@@ -102,7 +102,18 @@ def test_numpy_rollout_equals_T_step_calls(slip, mode):
     s1, s2 = e1.get_state(), e2.get_state()
     for key in s1:
         np.testing.assert_array_equal(s1[key], s2[key])
-    e1.close(); e2.close()
+    # the default, infos="last" (T - 1 fused steps + one full step), on a third twin: the same trajectories, the T-th step's infos
+    e3, e4 = _twins(n, slip, mode, "numpy")
+    e3.reset(); e4.close()
+    O3, R3, TE3, TR3, I3 = e3.rollout(T, acts)
+    for ag in ags:
+        np.testing.assert_array_equal(O3[ag], O[ag]); np.testing.assert_array_equal(R3[ag], R[ag])
+        np.testing.assert_array_equal(TE3[ag], TE[ag]); np.testing.assert_array_equal(TR3[ag], TR[ag])
+        np.testing.assert_array_equal(I3[ag]["p"], I[ag]["p"][-1])
+        np.testing.assert_array_equal(I3["final_observation"][ag], I["final_observation"][ag][-1])
+    np.testing.assert_array_equal(I3["_final_observation"], I["_final_observation"][-1])
+    np.testing.assert_array_equal(I3["reward_int8"], I["reward_int8"])
+    e1.close(); e2.close(); e3.close()
 
 
 def test_one_step_rollout_and_argument_checks():
