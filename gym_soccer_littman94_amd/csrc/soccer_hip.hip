@@ -79,6 +79,8 @@ struct soccer_handle {
     unsigned long long stamp_prev = 0;      // ... from this value (what the slot held when the replay was enqueued)
     unsigned long long swar_launch_lanes = kSwarLaunchLanes;   // lanes per step_kernel_swar / rollout_swar_kernel launch (SOCCER_SWAR_LAUNCH_LANES: tests of the split)
     int rollout_pref = 0;                   // SOCCER_ROLLOUT=1 (A/B runs, tests of the fallback): never the byte-parallel rollout
+    SlipF64* d_slip_f64 = nullptr;          // SLIPM == 3: nominal float64 slip thresholds (step_kernel_swar with caller-supplied uniforms)
+    uint32_t* d_worklist = nullptr;         // ... and the groups it leaves to the exact walk: [n / 4] indices + the count behind them
     unsigned long long* d_traj_hist = nullptr;   // soccer_trajectory_returns: u64[3] the kernel adds into
     void* comm = nullptr; int comm_world = 0, comm_rank = 0;   // soccer_comm_init: the RCCL communicator of this handle's device
     unsigned long long* d_comm_scratch = nullptr;   // 64 B for the small reductions (barrier, histogram, clocks)
@@ -136,7 +138,7 @@ static void free_handle(soccer_handle* h) {
     if (h->mapped) { if (h->d_state) (void)hipHostFree(h->d_state); h->d_state = nullptr; if (h->stage_host) (void)hipHostFree(h->stage_host); h->stage_host = nullptr; h->stage_dev = nullptr; }
     comm_release(h);
     void* bufs[] = {h->d_state, h->d_lut, h->d_nc, h->d_isd, h->d_policy[0], h->d_policy[1], h->d_tick, h->d_hist, h->stage_dev, h->d_sub, h->d_slip_lut, h->d_slip_step_lut,
-                    h->d_traj_hist, h->d_comm_scratch};
+                    h->d_traj_hist, h->d_comm_scratch, h->d_slip_f64, h->d_worklist};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (void* b : h->plan_bufs) if (b) (void)hipFree(b);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -281,6 +283,14 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_slip_step_lut), img.size() * sizeof(uint32_t)));
             CREATE_TRY(hipMemcpy(h->d_slip_step_lut, img.data(), img.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
+        {
+            SlipF64 F{};
+            for (int i = 0; i < 9; ++i) F.B[i] = ST.B[i];
+            for (int i = 0; i < 4; ++i) F.w[i] = ST.w[i];
+            F.act_pack = ST.act_pack; F.nb = ST.nb;
+            CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_slip_f64), sizeof F));
+            CREATE_TRY(hipMemcpy(h->d_slip_f64, &F, sizeof F, hipMemcpyHostToDevice));
+        }
         h->slip_c = swar::SlipConsts{};
         for (int i = 0; i < 9; ++i) h->slip_c.CB[i] = ST.CB[i];
         h->slip_c.c_off = ST.c_off;
@@ -330,6 +340,7 @@ extern "C" int soccer_create(const soccer_config* cfg, soccer_handle** out) {
     if (prop.sharedMemPerBlockOptin > 0) h->lds_limit = prop.sharedMemPerBlockOptin;
     else if (prop.sharedMemPerBlock > 0) h->lds_limit = prop.sharedMemPerBlock;
     CREATE_TRY(hipStreamSynchronize(h->stream));
+    CREATE_TRY(hipDeviceSynchronize());      // the hipMemset / hipMemcpy calls above went to the null stream, which a non-blocking stream does not wait for
 #undef CREATE_TRY
     *out = h;
     return SOCCER_OK;
@@ -430,6 +441,16 @@ extern "C" int batched_reset(soccer_handle* h, const uint8_t* mask, const double
 
 template <class T> static inline T* off(T* p, unsigned long long lanes) { return p ? p + lanes : nullptr; }   // NULL stays NULL
 
+// the work list of step_kernel_swar<.., SLIPM = 3, ..>: one index per 4-lane group of the handle, the count 16 bytes behind them
+static bool ensure_worklist(soccer_handle* h) {
+    if (h->d_worklist) return true;
+    const size_t words = (size_t)(h->P.n >> 2) + 8;
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_worklist), words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); h->d_worklist = nullptr; return false; }
+    // (on the handle's own stream: a memset on the null stream is not ordered with a non-blocking stream's kernels)
+    if (hipMemsetAsync(h->d_worklist, 0, words * sizeof(uint32_t), h->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
+
 template <bool EXPLICIT_U, bool VEC, bool SHARED>
 static void launch_step3(soccer_handle* h, const KernelParams& P, const StepIO& io) {
     const int grid = grid_for(h, (P.n + 3) / 4);
@@ -443,7 +464,12 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
     const bool swar_fit = vec && shared && h->swar_ok && (!h->slip || h->slip_swar_ok) && aligned(io.last_return, 4);
     // caller-supplied uniforms at slip_prob == 0: floor(4u) is the reference's decision for any double (step_kernel_swar, EXPL)
     const bool expl = explicit_u && !policy_only && !h->slip && aligned(io.u_step, 16) && aligned(io.u_reset, 16);
-    if ((policy_only || !explicit_u || expl) && swar_fit) {
+    // ... and at slip_prob > 0 the float64 decision against the nominal thresholds (SLIPM = 3); the groups it cannot decide safely go
+    // to the per-lane kernel's exact walk through a work list (one extra small launch per call)
+    const bool expl_slip = explicit_u && !policy_only && h->slip && io.u_step && aligned(io.u_step, 16) && aligned(io.u_reset, 16) &&
+                           vec && shared && h->swar_ok && aligned(io.last_return, 4) && (P.n >> 2) < 0xffffffffull &&
+                           (h->d_worklist || (!h->capturing && ensure_worklist(h)));      // (no allocation inside a capture: the per-lane kernel then)
+    if (((policy_only || !explicit_u || expl) && swar_fit) || expl_slip) {
         // the byte-parallel kernel (four lanes stay packed in their dwords, no rule-table reads)
         // which outputs the launch needs decides the instantiation: 0 the four result streams, 1 + the gym floats /
         // finished / last_return, 2 + final_obs / prob_code / episode histogram
@@ -453,7 +479,7 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
 #define SWAR_ARGS P.state + c0, P.state_stride, off(io.act_a, c0), off(io.act_b, c0), (h->capturing ? P.tick_in : nullptr), cn, (unsigned long long)(h->tick - 1), Q
 #define SWAR_GO(OV, SV, PV, XV) do { if (h->swar_c.small) hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 1, XV>), gh, b, 0, h->stream, SWAR_ARGS); \
                                      else hipLaunchKernelGGL((step_kernel_swar<OV, SV, PV, 0, XV>), gh, b, 0, h->stream, SWAR_ARGS); } while (0)
-#define SWAR_SLIP(OV, PV) do { if (expl) SWAR_GO(OV, 0, PV, true); else if (!h->slip) SWAR_GO(OV, 0, PV, false); \
+#define SWAR_SLIP(OV, PV) do { if (expl_slip) SWAR_GO(OV, 3, PV, true); else if (expl) SWAR_GO(OV, 0, PV, true); else if (!h->slip) SWAR_GO(OV, 0, PV, false); \
                                else if (h->d_slip_step_lut) SWAR_GO(OV, 2, PV, false); else SWAR_GO(OV, 1, PV, false); } while (0)
 #define SWAR_OUT(PV) do { if (out == 2) SWAR_SLIP(2, PV); else if (out == 1) SWAR_SLIP(1, PV); else SWAR_SLIP(0, PV); } while (0)
         // The kernel's byte offsets are 32-bit (soccer_kernels.hpp): a handle beyond kSwarLaunchLanes lanes is stepped by
@@ -468,8 +494,15 @@ static void launch_step(soccer_handle* h, const KernelParams& P, const StepIO& i
                          (h->cfg.flags & SOCCER_F_STREAM_ACTIONS) ? 1u : 0u, P.policy_a, P.policy_b,
                          off(io.obs, c0), off(io.reward, c0), off(io.terminated, c0), off(io.truncated, c0), off(io.prob_code, c0),
                          off(io.final_obs, c0), off(io.reward_a_f32, c0), off(io.reward_b_f32, c0), off(io.finished, c0),
-                         off(io.last_return, c0), off(io.u_step, c0), off(io.u_reset, c0)};
+                         off(io.last_return, c0), off(io.u_step, c0), off(io.u_reset, c0),
+                         h->d_slip_f64, h->d_worklist, h->d_worklist ? h->d_worklist + (h->P.n >> 2) + 4 : nullptr};
             if (P.policy_a || P.policy_b) SWAR_OUT(true); else SWAR_OUT(false);
+            if (expl_slip) {
+                // the groups of THIS part that were listed: the per-lane kernel, one workgroup, same tick (it publishes nothing)
+                KernelParams R = P; R.first = c0; R.n = cn; R.tick_out = nullptr;
+                StepIO jo = io; jo.worklist = h->d_worklist; jo.work_count = h->d_worklist + (h->P.n >> 2) + 4;
+                hipLaunchKernelGGL((step_kernel<true, true, true, true>), dim3(1), dim3(kBlock), 0, h->stream, R, jo);
+            }
         }
 #undef SWAR_OUT
 #undef SWAR_SLIP
@@ -514,7 +547,7 @@ extern "C" int batched_step_ex(soccer_handle* h, const soccer_step_args* a) {
     KernelParams P = h->P;
     bind_tick(h, P, 1);
     StepIO io{a->act_a, a->act_b, a->u_step, a->u_reset, a->obs, a->reward, a->terminated, a->truncated,
-              a->prob_code, a->final_obs, a->last_return, a->reward_a_f32, a->reward_b_f32, a->finished};
+              a->prob_code, a->final_obs, a->last_return, a->reward_a_f32, a->reward_b_f32, a->finished, nullptr, nullptr};
     const unsigned long long n = h->P.n, n4 = vec ? (n & ~3ull) : 0ull;
     if (n4) { P.first = 0; P.n = n4; launch_step(h, P, io, explicit_u, true); }
     if (n4 < n) {               // ragged tail (or everything, when the buffers are not dword-aligned)

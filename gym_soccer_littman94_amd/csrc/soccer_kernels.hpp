@@ -87,6 +87,9 @@ struct StepIO {
     uint16_t* obs; int8_t* reward; uint8_t* terminated; uint8_t* truncated;
     uint8_t* prob_code; uint16_t* final_obs; int8_t* last_return;
     float* reward_a_f32; float* reward_b_f32; uint8_t* finished;      // the gym surface's float rewards / terminated | truncated
+    // the 4-lane groups step_kernel_swar<.., SLIPM = 3, ..> left to the exact float64 walk (a caller's uniform within 2^-40 of a
+    // nominal threshold): the per-lane kernel then steps exactly these groups and zeroes the count; nullptr: every group
+    const uint32_t* worklist; uint32_t* work_count;
 };
 
 struct ResetIO {
@@ -721,7 +724,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
     Tables T; T.lut = P.lut; T.nc = P.next_cell; T.isd = P.isd;
     bool mis = false;
     uint32_t bad_act = 0u;
-    for (unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; g < groups; g += stride) {
+    const unsigned long long todo = IO.worklist ? (unsigned long long)*IO.work_count : groups;      // (one workgroup when listed)
+    for (unsigned long long k = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; k < todo; k += stride) {
+        const unsigned long long g = IO.worklist ? (unsigned long long)IO.worklist[k] : k;
         const unsigned long long i0 = P.first + (g << 2);
         const int cnt = VEC ? 4 : ((P.n - (g << 2)) < 4ull ? (int)(P.n - (g << 2)) : 4);
         const uint8_t* sp = P.state;
@@ -821,6 +826,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KernelParams P, const
     if (bad_act) P.misuse[1] = 1u;
     if (stats) hist.flush(P);
     if (P.tick_out) publish_tick(P, tick, 1ull);
+    if (IO.worklist) {                       // launched as ONE workgroup: everyone has read the count, the list is consumed
+        __syncthreads();
+        if (threadIdx.x == 0) *IO.work_count = 0u;
+    }
 }
 
 // The instantiation every Philox-driven, dword-aligned, 4-outputs-only step takes (bench.py's path):
@@ -956,6 +965,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel_hot(uint8_t* state, unsign
 // Takes every Philox-driven, dword-aligned step of a slip_prob == 0 handle whose pitch fits the byte arithmetic
 // (swar::fits: every golden pitch up to 11x7 does).  GENERAL = false is the steady state of an auto-resetting
 // handle (no frozen lane, no lane in a goal tuple); FULL adds final_obs and prob_code (VectorSoccerEnv).
+// slip_prob > 0 with the caller's uniforms: the float64 form of the slip decision (SlipTables::B / w / act_pack / nb)
+struct SlipF64 { double B[9]; double w[4]; unsigned long long act_pack; uint32_t nb; uint32_t pad_; };
 struct SwarParams {
     swar::Consts C;
     uint32_t key0, key1;
@@ -972,7 +983,10 @@ struct SwarParams {
     uint8_t* prob_code; uint16_t* final_obs;                          // OUT == 2
     float* reward_a_f32; float* reward_b_f32; uint8_t* finished; int8_t* last_return;   // OUT >= 1
     const double* u_step; const double* u_reset;   // EXPL: caller-supplied uniforms (16-byte aligned; either may be nullptr: Philox then)
+    const SlipF64* f64;                            // SLIPM == 3: the nominal float64 thresholds of the slip list
+    uint32_t* worklist; uint32_t* work_count;      // SLIPM == 3: groups left to the exact walk (see StepIO)
 };
+
 
 // OUT — which outputs the instantiation can write (every pointer may still be NULL):
 //   0  obs / reward / terminated / truncated: the 8-argument batched_step (19 B per env-step)
@@ -1011,7 +1025,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
                                                            const SwarParams Q) {
     constexpr bool FULL = OUT == 2;
     constexpr bool SLIP = SLIPM != 0;
-    static_assert(!EXPL || SLIPM == 0, "caller-supplied uniforms take the byte-parallel step only at slip_prob == 0");
+    static_assert((SLIPM == 3) ? EXPL : (!EXPL || SLIPM == 0), "caller-supplied uniforms: SLIPM 0 (dyadic lists) or 3 (float64 slip decision)");
     static_assert(kSlipStepBuckets == 64 * 16 && kSlipThresholds <= 64, "one 16-byte piece of the table per lane of a wave");
     const unsigned long long g = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     const bool active = (g << 2) < n;                                // n is a multiple of 4 here
@@ -1069,13 +1083,18 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
     }
     // EXPL: the four lanes' uniforms, as floor(4u) (two bits each) — behind the state loads, ahead of the Philox block
     uint32_t xq = 0u, xr = 0u;
+    double us0 = 0.0, us1 = 0.0, us2 = 0.0, us3 = 0.0;               // SLIPM == 3: the step uniforms themselves
+    if (SLIPM == 3 && active) {
+        const double2 a = *reinterpret_cast<const double2*>(Q.u_step + i0), b = *reinterpret_cast<const double2*>(Q.u_step + i0 + 2);
+        us0 = a.x; us1 = a.y; us2 = b.x; us3 = b.y;
+    }
     if (EXPL && active) {
         auto quarters = [&](const double* base) {
             const double2 a = *reinterpret_cast<const double2*>(base + i0), b = *reinterpret_cast<const double2*>(base + i0 + 2);
             return (uint32_t)(sane_uniform(a.x) * 4.0) | ((uint32_t)(sane_uniform(a.y) * 4.0) << 8) |
                    ((uint32_t)(sane_uniform(b.x) * 4.0) << 16) | ((uint32_t)(sane_uniform(b.y) * 4.0) << 24);
         };
-        if (Q.u_step) xq = quarters(Q.u_step);
+        if (SLIPM != 3 && Q.u_step) xq = quarters(Q.u_step);
         if (Q.u_reset) xr = quarters(Q.u_reset);
     }
     // the tick: by value for eager launches, from the device slot for captured ones (read after the data loads are issued)
@@ -1109,7 +1128,45 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         swar::Out o;
         uint32_t sa = 0u, sb = 0u, cls4 = 0u;
         swar::Rand4 rnd;
-        if (SLIP) {
+        bool listed = false;                                             // SLIPM == 3: the group goes to the exact walk of the per-lane kernel
+        if (SLIPM == 3) {
+            // The caller's uniform against the NOMINAL thresholds of the slip list — the cumulative weights of the active
+            // combinations, then the quarter points of the selected one.  The reference's sequential float64 sums differ from
+            // these by < 1e-14 whatever the list's shape (lane_step, fast decision), so a uniform farther than 2^-40 from every
+            // threshold it is compared with is decided as the reference decides it; a group with a lane inside that margin (or
+            // beyond the last threshold) is left to the per-lane kernel's exact walk: listed, nothing stored here.
+            const SlipF64& F = *Q.f64;
+            const double us[4] = {us0, us1, us2, us3};
+            uint32_t c4 = 0u, k4 = 0u; bool near = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double u = sane_uniform_walk(us[j]);
+                uint32_t idx = 0u; double S0 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const double bi = F.B[i];                         // wave-uniform; +inf past the last active one
+                    const bool ge = u >= bi;
+                    idx += ge ? 1u : 0u; S0 = ge ? bi : S0;
+                    near |= fabs(u - bi) < 0x1.0p-40;
+                }
+                near |= idx >= F.nb;
+                const uint32_t c = (uint32_t)((F.act_pack >> (4u * idx)) & 0xfull);
+                constexpr uint32_t CL2 = 0u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12) | (3u << 14) | (3u << 16);
+                const uint32_t cl = (CL2 >> (2u * c)) & 3u;           // weight class of combination c (:211-222), as in lane_step
+                const double wq = (cl & 2u) ? ((cl & 1u) ? F.w[3] : F.w[2]) : ((cl & 1u) ? F.w[1] : F.w[0]);
+                const double q = wq * 0.25, t1 = S0 + q, t2 = t1 + q, t3 = t2 + q;
+                const uint32_t kq = (u >= t1 ? 1u : 0u) + (u >= t2 ? 1u : 0u) + (u >= t3 ? 1u : 0u);
+                near |= fabs(u - t1) < 0x1.0p-40; near |= fabs(u - t2) < 0x1.0p-40; near |= fabs(u - t3) < 0x1.0p-40;
+                c4 |= c << (8 * j); k4 |= kq << (8 * j);
+            }
+            if (near) {
+                const uint32_t slot = atomicAdd(Q.work_count, 1u);
+                Q.worklist[slot] = (uint32_t)g;
+                listed = true;                                            // nothing of this group is stored or counted here
+            }
+            swar::slip_moves4(c4, swar::canon4(aa), swar::canon4(ab), sa, sb, cls4);
+            rnd = swar::Rand4{k4 << 6, Q.u_reset ? (xr >> Q.C.isd_shift) : (swar::pack_byte0(blk.w[0], blk.w[1], blk.w[2], blk.w[3]) >> Q.C.isd_shift)};
+        } else if (SLIP) {
             uint32_t k4 = 0u;
             if (SLIPM == 2) {
                 const uint32_t p4 = swar::slip_count4_lut<kSlipStepBucketBits, kSlipStepCompares>(slip_lut, slip_thr, blk.w[0], blk.w[1], blk.w[2], blk.w[3]);
@@ -1127,6 +1184,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
                 if (Q.u_reset) rnd.rs = xr >> Q.C.isd_shift;
             }
         }
+        if (!listed) {
         // Frozen lanes and goal tuples exist only without auto-reset or after a state injection; a thread none of whose lanes is
         // in either condition (nearly every thread of an auto-resetting handle) takes the step without the code for them —
         // 31 vector instructions fewer, 12 for the test: in this kernel every instruction shows (5.6 ns).
@@ -1179,6 +1237,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_swar(const uint8_t* state_
         }
         if (o.frozen) Q.misuse[0] = 1u;
         if (o.bad_action) Q.misuse[1] = 1u;
+        }
         // (published last: a store in flight ahead of the loads' waits would turn them into waits for everything — loads and
         // stores share the wave's counter and complete out of order with respect to each other)
         if (Q.tick_out && blockIdx.x == 0 && threadIdx.x == 0) *Q.tick_out = tick + 1ull;
