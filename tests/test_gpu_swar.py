@@ -756,3 +756,54 @@ def test_a_rollout_split_into_several_launches_is_the_same_rollout(slip, monkeyp
     np.testing.assert_array_equal(hist, o.hist)
     assert misuse == 0 and b.tick == o.tick
     b.close()
+
+
+@pytest.mark.parametrize("slip", [0.5, 0.2, 0.25])
+@pytest.mark.parametrize("full", [False, True])
+def test_caller_uniforms_on_slip_lists_through_the_byte_parallel_step(slip, full):
+    """batched_step_ex with u_step / u_reset at slip_prob > 0 (step_kernel_swar<.., SLIPM = 3, ..>): the float64 decision against the
+    nominal thresholds, with every group that holds a uniform within 2^-40 of one handed to the per-lane kernel's exact walk through
+    the work list.  Three regimes per step: random uniforms (nothing listed), a mix, and EVERY lane on a threshold (everything
+    listed: the whole batch goes through the one-workgroup tail) — eagerly and as a replayed graph (the list's count must come
+    back to zero every time)."""
+    n, steps = 8192, 12
+    rng = np.random.default_rng(int(slip * 100) + full)
+    b = SoccerBatch(n, 5, 4, slip, seed=3, autoreset=True, step_stats=full)
+    o = Oracle(5, 4, slip, n=n, seed=3, autoreset=True)
+    b.reset(); o.reset()
+    c0 = (1 - slip) * (1 - slip); c1 = (1 - slip) * slip * 0.5
+    on_thr = np.array([c0, np.nextafter(c0, 0), np.nextafter(c0, 1), c0 + c1, c0 + c1 + c1, c0 * 0.5, c0 * 0.25, c0 * 0.75, 0.0, 1.0 - 2.0 ** -53])
+    A = b.alloc(n, np.int8); B = b.alloc(n, np.int8); U = b.alloc(n, np.float64); UR = b.alloc(n, np.float64)
+    obs = b.alloc(n, np.uint16); rew = b.alloc(n, np.int8); te = b.alloc(n, np.uint8); tr = b.alloc(n, np.uint8)
+    code = b.alloc(n, np.uint8) if full else None; fin = b.alloc(n, np.uint16) if full else None
+
+    def one(k, captured=None):
+        a = rng.integers(0, 5, size=(2, n), dtype=np.int8)
+        regime = k % 3
+        u = rng.random(n) if regime == 0 else on_thr[rng.integers(0, len(on_thr), n)] if regime == 2 else \
+            np.where(rng.random(n) < 0.3, on_thr[rng.integers(0, len(on_thr), n)], rng.random(n))
+        ur = rng.random(n)
+        A.upload(a[0]); B.upload(a[1]); U.upload(u); UR.upload(ur)
+        if captured is None:
+            b.step(A, B, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin, u_step=U, u_reset=UR)
+        else:
+            b.graph_launch(captured, 1)
+        c = o.step(a[0], a[1], u_step=u, u_reset=ur)
+        np.testing.assert_array_equal(obs.download(), c["obs"], err_msg="obs, step %d regime %d" % (k, regime))
+        np.testing.assert_array_equal(rew.download(), c["reward"]); np.testing.assert_array_equal(te.download(), c["terminated"])
+        np.testing.assert_array_equal(tr.download(), c["truncated"])
+        if full:
+            np.testing.assert_array_equal(code.download(), c["prob_code"], err_msg="prob_code, step %d regime %d" % (k, regime))
+            np.testing.assert_array_equal(fin.download(), c["final_obs"])
+    for k in range(steps):
+        one(k)
+    b.graph_begin()
+    b.step(A, B, obs=obs, reward=rew, terminated=te, truncated=tr, prob_code=code, final_obs=fin, u_step=U, u_reset=UR)
+    g = b.graph_end()
+    for k in range(steps):
+        one(k, captured=g)
+    _state_equal(b, o)
+    if full:
+        np.testing.assert_array_equal(b.stats()[0], o.hist)
+    assert b.misuse() == 0 and b.tick == o.tick
+    b.graph_destroy(g); b.close()
